@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE config 2 -- batched 1-D complex64 FFT, N = 1024 x
+65536 signals, fused Hann window + power spectrum, per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch (already resident in HBM).
+With N > 1 every rank transforms its own batch of 65536 signals (independent
+signals shard with no data-path collective): weak scaling, value = whole-job
+GFLOP/s.  Rank 0 prints one JSON line.  `roofline` prices the dominant kernel
+(the only kernel of this workload) by its algorithmic bytes -- 8 B read + 4 B
+written per point -- over its measured average launch time; `cpu_baseline` is the
+reference's own numpy chain (np.hanning, multiply, np.fft.fft, np.abs()**2) timed
+on the host, single thread, on a bounded sample of the same signals.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+N_POINTS = 1024
+BATCH = 65536
+DT = 0.01
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=N_POINTS, help="transform length (default: the headline 1024)")
+    ap.add_argument("--batch", type=int, default=BATCH, help="signals per GPU (default: the headline 65536)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def synth(batch, n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    x = np.empty((batch, n), dtype=np.complex64)
+    chunk = 8192
+    for lo in range(0, batch, chunk):
+        hi = min(batch, lo + chunk)
+        x[lo:hi].real = rng.standard_normal((hi - lo, n), dtype=np.float32)
+        x[lo:hi].imag = rng.standard_normal((hi - lo, n), dtype=np.float32)
+    return x
+
+
+def cpu_baseline(x_host, n):
+    """The reference's numpy chain on the first rows of the same input, 1 thread."""
+    import numpy as np
+    from oracle import spectral_oracle as so
+    rows = min(len(x_host), 16384)
+    sample = x_host[:rows]
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        so.reference_numpy_chain(sample)
+        best = min(best, time.perf_counter() - t0)
+    flops = 5.0 * n * math.log2(n) * rows
+    return {"value": flops / best / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"first {rows} of the {len(x_host)} signals (N={n}, complex64), best of 3; "
+                      "np.hanning * x -> np.fft.fft -> np.abs()**2 as final2.py:139-145; "
+                      f"{os.cpu_count()} host cpus visible, numpy {np.__version__} pocketfft is single-threaded"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import fft_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    n, batch = args.n, args.batch
+    log2n = int(round(math.log2(n)))
+    assert 1 << log2n == n, "bench workload is a power-of-two length"
+
+    x_host = synth(batch, n, seed=rank)
+    d_x = torch.from_numpy(x_host).cuda()
+    d_s = torch.empty((batch, n), dtype=torch.float32, device="cuda")
+    plan = fft_amd.Plan(n, batch=batch, dtype=fft_amd.C64, flags=fft_amd.HANN | fft_amd.POWER)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.exec(d_x, d_s, scale=DT, stream=stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # kernel launch durations, measured with events on the launch stream
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        stops[i].record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    kern_avg_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
+
+    flops_step = 5.0 * n * log2n * batch * world
+    alg_bytes = (8 + 4) * n * batch                       # per launch, per GPU
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath) and n == N_POINTS and batch == BATCH:
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("bytes_per_launch")
+    line = {
+        "metric": "FFT GFLOP/s (5N·log2N) + achieved HBM GB/s vs roofline",
+        "value": flops_step * args.steps / elapsed / 1e9,
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (numpy default_rng(rank), i.i.d. standard normal re/im, complex64)",
+        "config": {"workload": f"batched 1-D complex64 FFT, N={n} x {batch} signals per GPU, "
+                               "fused Hann window + power spectrum (BASELINE config 2)",
+                   "n": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective"},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / kern_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg_bytes / kern_avg_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": "fft_lds_kernel (hann+power)",
+                     "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(x_host, n)
+    else:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    plan.destroy()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""ctypes binding of libmfft.so (the C ABI declared in include/mfft.h).
+
+The library is built in-tree by ``make -C fft_amd/csrc`` (or
+``__graft_entry__.build()``) into ``fft_amd/lib/libmfft.so``.  There is no CPU
+fallback: if the shared object is missing or no GPU is visible, every call
+raises -- the product path never computes a transform on the host.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmfft.so")
+
+C64, C128 = 0, 1
+HANN, POWER, DEMOD, REAL_IN, STATS, INVERSE = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+
+OK, E_INVALID, E_UNSUPPORTED, E_NOMEM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4, -5
+
+# every symbol include/mfft.h declares: (name, restype, argtypes)
+_vp, _i64, _dbl, _int, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_uint32
+_dblp = ctypes.POINTER(ctypes.c_double)
+SIGNATURES = {
+    "mfft_version": (_int, []),
+    "mfft_device_count": (_int, []),
+    "mfft_strerror": (ctypes.c_char_p, [_int]),
+    "mfft_last_error": (ctypes.c_char_p, []),
+    "mfft_plan_1d": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32]),
+    "mfft_plan_destroy": (_int, [_vp]),
+    "mfft_plan_workspace_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
+    "mfft_plan_launches": (_int, [_vp, ctypes.POINTER(_int)]),
+    "mfft_exec": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp]),
+    "mfft_exec_host": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp]),
+    "mfft_normalize_by_max": (_int, [_vp, _vp, _i64, _vp, _int, _vp]),
+    "mfft_transpose": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "mfft_twiddle_tile": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+}
+
+_lib = None
+
+
+class MfftError(RuntimeError):
+    """A libmfft call failed for a reason other than a bad argument."""
+
+
+def load():
+    """Load libmfft.so (once) and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfftError(
+                f"{LIB_PATH} is missing: build it with `make -C fft_amd/csrc` "
+                "(there is no CPU fallback for the spectral path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    """Translate a return code: bad arguments -> ValueError, the rest -> MfftError."""
+    if rc == OK:
+        return
+    lib = load()
+    detail = lib.mfft_last_error().decode("utf-8", "replace")
+    what = lib.mfft_strerror(rc).decode()
+    if rc == E_INVALID:
+        raise ValueError(detail or what)
+    raise MfftError(f"{what}: {detail}" if detail else what)
+
+
+def device_count() -> int:
+    n = load().mfft_device_count()
+    if n < 0:
+        check(n)
+    return n

@@ -1,0 +1,88 @@
+// Host-side plumbing shared by the translation units of libmfft.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mfft.h"
+#include "fft_core.h"
+
+namespace mfft {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define MFFT_HIP(call)                                                        \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return ::mfft::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// exp(-2*pi*i*k/n) in long double with exact quarter-turn reduction.
+void unit_root(int64_t k, int64_t n, long double* re, long double* im);
+
+inline int ilog2(int64_t n)
+{
+    int l = 0;
+    while ((int64_t(1) << l) < n) ++l;
+    return l;
+}
+inline bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// ---------------------------------------------------------------------------
+// Arguments of the LDS-resident Stockham kernels (one struct for all variants;
+// fields a variant does not use are ignored).
+// ---------------------------------------------------------------------------
+template <typename T> struct KArgs {
+    const void* in;        // complex (or real when real_in) input
+    void* out;             // complex output, or real power spectrum
+    const cx<T>* tw;       // per-pass twiddle tables, concatenated
+    const T* win;          // real window of n_in samples, or nullptr
+    const cx<T>* pre;      // complex premultiplier (window*demod*chirp) of n_in samples, or nullptr
+    const cx<T>* post;     // complex postmultiplier of n_out bins, applied after conj_out, or nullptr
+    double* stats;         // 3 doubles per transform, or nullptr
+    int64_t batch;
+    int64_t in_stride;     // elements between consecutive signals in `in`
+    int64_t out_stride;    // elements between consecutive spectra in `out`
+    int n_in;              // samples present per signal (<= N); the rest are zero
+    int n_out;             // bins stored per signal (<= N)
+    int real_in;           // input elements are real
+    int conj_in;           // conjugate on load  (inverse transform = conj . forward . conj)
+    int conj_out;          // conjugate on store
+    T scale;
+};
+
+// kernel variants
+enum Variant {
+    V_PLAIN = 0,       // complex in (full length, contiguous) -> scaled complex out
+    V_HANN_POWER = 1,  // complex in * register-resident window -> power out   (BASELINE config 2)
+    V_GEN_CPLX = 2,    // general prologue (pad / window / premultiplier / real / conj) -> complex out
+    V_GEN_POWER = 3,   // general prologue -> power out (+ optional per-signal stats)
+    V_COUNT = 4
+};
+
+// Description of how one power-of-two length is decomposed inside the LDS kernel.
+struct LdsGeometry {
+    int n, p, tx, block, slots, npass, radix[4];
+    size_t lds_bytes;
+    size_t tw_elems;       // total twiddle-table entries
+};
+
+// Largest single-kernel lengths
+constexpr int kMaxLdsLog2C64 = 14;   // 16384 points, 128 KiB + padding
+constexpr int kMaxLdsLog2C128 = 13;  // 8192 points
+
+bool lds_geometry(int dtype, int log2n, LdsGeometry* g);
+
+// Launch the LDS kernel for 2^log2n points.  grid <= 0 lets the launcher pick a
+// persistent grid from the device's CU count.
+int launch_lds_c64(int log2n, int variant, const KArgs<float>& a, int grid, hipStream_t s);
+int launch_lds_c128(int log2n, int variant, const KArgs<double>& a, int grid, hipStream_t s);
+
+// Fill a host vector with the per-pass twiddle tables of the LDS kernel.
+void build_lds_twiddles(const LdsGeometry& g, std::vector<long double>* re, std::vector<long double>* im);
+
+int device_cu_count();
+
+}  // namespace mfft

@@ -1,0 +1,158 @@
+// Butterflies and Stockham index algebra shared by every kernel in mfft.hip.
+//
+// Everything here is a pure function of registers: no memory access, no thread
+// ids.  The same templates are compiled for gfx950 device code by hipcc and, for
+// the index-algebra unit test (tests/csrc/emul_stockham.cpp), for the host by g++.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MFFT_HD __host__ __device__ __forceinline__ constexpr
+#else
+#define MFFT_HD inline constexpr
+#endif
+
+namespace mfft {
+
+template <typename T> struct cx { T x, y; };
+
+template <typename T> MFFT_HD cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> MFFT_HD cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> MFFT_HD cx<T> cmul(cx<T> a, cx<T> b)
+{
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// a * conj(b)
+template <typename T> MFFT_HD cx<T> cmulc(cx<T> a, cx<T> b)
+{
+    return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+// multiply by -i (forward quarter turn) / +i
+template <typename T> MFFT_HD cx<T> mul_mi(cx<T> a) { return {a.y, -a.x}; }
+template <typename T> MFFT_HD cx<T> mul_pi(cx<T> a) { return {-a.y, a.x}; }
+
+// ---------------------------------------------------------------------------
+// Forward DFT of R points held in registers, natural order in and out:
+//   v[q] <- sum_i v[i] * exp(-2*pi*i * i*q / R)
+// R = 2, 4, 8, 16.  Built as decimation in time from radix-4 kernels with the
+// small constant twiddles folded in (W8^1 = (1-i)/sqrt2 etc.).
+// ---------------------------------------------------------------------------
+
+template <typename T> MFFT_HD void bfly2(cx<T>& a, cx<T>& b)
+{
+    cx<T> t = a - b;
+    a = a + b;
+    b = t;
+}
+
+template <typename T> MFFT_HD void dft4(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3)
+{
+    cx<T> s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = mul_mi(a1 - a3);
+    a0 = s02 + s13;
+    a1 = d02 + d13;
+    a2 = s02 - s13;
+    a3 = d02 - d13;
+}
+
+template <typename T> struct consts {
+    static constexpr T s2 = (T)0.70710678118654752440084436210484903928L;   // sqrt(1/2)
+    static constexpr T c16 = (T)0.92387953251128675612818318939678828682L;  // cos(pi/8)
+    static constexpr T s16 = (T)0.38268343236508977172845998403039886676L;  // sin(pi/8)
+};
+
+// a * W8^1 = a * (1 - i)/sqrt2 ; a * W8^3 = a * (-1 - i)/sqrt2
+template <typename T> MFFT_HD cx<T> mul_w8_1(cx<T> a) { return {(a.x + a.y) * consts<T>::s2, (a.y - a.x) * consts<T>::s2}; }
+template <typename T> MFFT_HD cx<T> mul_w8_3(cx<T> a) { return {(a.y - a.x) * consts<T>::s2, -(a.x + a.y) * consts<T>::s2}; }
+
+template <typename T> MFFT_HD void dft8(cx<T>* v)
+{
+    // two radix-4 on even / odd inputs, then radix-2 combine with W8^k
+    dft4(v[0], v[2], v[4], v[6]);
+    dft4(v[1], v[3], v[5], v[7]);
+    cx<T> t1 = mul_w8_1(v[3]), t2 = mul_mi(v[5]), t3 = mul_w8_3(v[7]);
+    cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + t1; v[5] = e1 - t1;
+    v[2] = e2 + t2; v[6] = e2 - t2;
+    v[3] = e3 + t3; v[7] = e3 - t3;
+}
+
+// a * W16^k for the constant k that appear in the 4x4 decomposition
+template <typename T, int K> MFFT_HD cx<T> mul_w16(cx<T> a)
+{
+    constexpr T c = consts<T>::c16, s = consts<T>::s16;
+    if constexpr (K == 0) return a;
+    else if constexpr (K == 1) return {a.x * c + a.y * s, a.y * c - a.x * s};       // (c - i s)
+    else if constexpr (K == 2) return mul_w8_1(a);
+    else if constexpr (K == 3) return {a.x * s + a.y * c, a.y * s - a.x * c};       // (s - i c)
+    else if constexpr (K == 4) return mul_mi(a);
+    else if constexpr (K == 6) return mul_w8_3(a);
+    else /* K == 9 */ return {-(a.x * c + a.y * s), a.x * s - a.y * c};             // (-c + i s) = -W16^1
+}
+
+template <typename T> MFFT_HD void dft16(cx<T>* v)
+{
+    // index i = i0 + 4*i1 : radix-4 over i1 for each i0, twiddle W16^(i0*k1), radix-4 over i0
+    dft4(v[0], v[4], v[8], v[12]);
+    dft4(v[1], v[5], v[9], v[13]);
+    dft4(v[2], v[6], v[10], v[14]);
+    dft4(v[3], v[7], v[11], v[15]);
+    // after the first step v[i0 + 4*k1] holds partial k1; apply W16^(i0*k1)
+    v[5] = mul_w16<T, 1>(v[5]);  v[9] = mul_w16<T, 2>(v[9]);   v[13] = mul_w16<T, 3>(v[13]);
+    v[6] = mul_w16<T, 2>(v[6]);  v[10] = mul_w16<T, 4>(v[10]); v[14] = mul_w16<T, 6>(v[14]);
+    v[7] = mul_w16<T, 3>(v[7]);  v[11] = mul_w16<T, 6>(v[11]); v[15] = mul_w16<T, 9>(v[15]);
+    // radix-4 over i0 for each k1: inputs v[0..3 + 4*k1], output q = k1 + 4*k0
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4(v[4], v[5], v[6], v[7]);
+    dft4(v[8], v[9], v[10], v[11]);
+    dft4(v[12], v[13], v[14], v[15]);
+    // now v[k0 + 4*k1] holds output q = k1 + 4*k0 : transpose the 4x4 index
+    cx<T> t;
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// Radix-R DFT of the R registers v[0], v[S], v[2S], ... (stride S), natural order.
+template <typename T, int R, int S> MFFT_HD void dft_strided(cx<T>* v)
+{
+    if constexpr (R == 1) {
+        (void)v;
+    } else if constexpr (R == 2) {
+        bfly2(v[0], v[S]);
+    } else if constexpr (R == 4) {
+        dft4(v[0], v[S], v[2 * S], v[3 * S]);
+    } else {
+        cx<T> w[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) w[i] = v[i * S];
+        if constexpr (R == 8) dft8(w); else dft16(w);
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i * S] = w[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stockham autosort index algebra for one pass of radix R over a length-N
+// transform whose already-combined sub-transform length is NS (product of the
+// radices of the earlier passes).  Butterfly j in [0, N/R):
+//   reads   x[j + i*(N/R)]                       i = 0..R-1
+//   twiddle x_i *= exp(-2*pi*i * (j mod NS) * i / (NS*R))
+//   writes  y[(j / NS)*NS*R + (j mod NS) + q*NS] q = 0..R-1
+// ---------------------------------------------------------------------------
+MFFT_HD int stockham_out_base(int j, int ns, int r)
+{
+    return (j / ns) * ns * r + (j % ns);
+}
+
+// LDS padding: one extra element after every 2^SHIFT elements (SHIFT >= 31 disables).
+template <int SHIFT> MFFT_HD int lds_pad(int pos)
+{
+    if constexpr (SHIFT >= 31) return pos;
+    else return pos + (pos >> SHIFT);
+}
+
+}  // namespace mfft

@@ -1,0 +1,43 @@
+// Instantiates the LDS-resident Stockham kernels for complex64 (fp32 butterflies)
+// and exports the size table (shared by both precisions) to the host code.
+#include "lds_kernel.h"
+
+namespace mfft {
+
+int launch_lds_c64(int log2n, int variant, const KArgs<float>& a, int grid, hipStream_t s)
+{
+    return launch_lds_any<float, kMaxLdsLog2C64>(log2n, variant, a, grid, s);
+}
+
+template <int L> static void fill_geometry(int dtype, LdsGeometry* g)
+{
+    using SC = SizeCfg<L>;
+    g->n = 1 << L;
+    g->p = SC::P;
+    g->tx = BlockCfg<L>::TX;
+    g->block = BlockCfg<L>::BLOCK;
+    g->slots = g->block / g->tx;
+    g->npass = SC::RD::npass;
+    for (int i = 0; i < 4; ++i) g->radix[i] = SC::RD::r[i];
+    g->lds_bytes = (SC::RD::npass > 1)
+                       ? (dtype == MFFT_C64 ? lds_bytes_for<float, L>() : lds_bytes_for<double, L>())
+                       : 0;
+    size_t tw = 0;
+    for (int s = 1; s < SC::RD::npass; ++s) tw += (size_t)tw_pass_elems<typename SC::RD>(s);
+    g->tw_elems = tw;
+}
+
+bool lds_geometry(int dtype, int log2n, LdsGeometry* g)
+{
+    const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
+    if (log2n < 1 || log2n > maxlog) return false;
+    switch (log2n) {
+#define MFFT_G(L) case L: fill_geometry<L>(dtype, g); return true;
+        MFFT_G(1) MFFT_G(2) MFFT_G(3) MFFT_G(4) MFFT_G(5) MFFT_G(6) MFFT_G(7)
+        MFFT_G(8) MFFT_G(9) MFFT_G(10) MFFT_G(11) MFFT_G(12) MFFT_G(13) MFFT_G(14)
+#undef MFFT_G
+    }
+    return false;
+}
+
+}  // namespace mfft

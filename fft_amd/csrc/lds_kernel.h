@@ -1,0 +1,386 @@
+// LDS-resident batched Stockham FFT for gfx950: one kernel transforms whole
+// signals of N = 2^k points without touching HBM between passes.
+//
+// Work decomposition.  A signal of N points is owned by TX = N/P threads, each
+// holding P points in registers.  A pass of radix R lets every thread run P/R
+// butterflies on its registers; between passes the points are exchanged through
+// LDS in Stockham (autosort) order, so no bit-reversal pass exists.  The read
+// side of every exchange is the same for all passes: thread t takes positions
+// t + TX*e (e < P), which is also the pattern of the global load that feeds the
+// first pass and of the global store that drains the last -- consecutive lanes
+// touch consecutive elements everywhere, in HBM and in LDS.
+//
+// When TX <= 64 a signal lives inside one wavefront: the exchange needs no
+// s_barrier (LDS instructions of one wave execute in order), and the waves of a
+// workgroup drift apart freely, which is what keeps HBM loads, butterflies and
+// stores of different signals overlapped on a CU.  For TX > 64 the exchange is
+// bracketed by workgroup barriers.
+//
+// Workgroups are persistent: the grid is sized to the machine and every
+// workgroup strides over the batch, so per-lane constants (window samples,
+// twiddles) are fetched once into registers and reused for every signal.
+#pragma once
+#include "common.h"
+
+namespace mfft {
+
+template <int R0, int R1, int R2, int R3> struct Radices {
+    static constexpr int r[4] = {R0, R1, R2, R3};
+    static constexpr int npass = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    static constexpr int ns(int s) { return s == 0 ? 1 : (s == 1 ? R0 : (s == 2 ? R0 * R1 : R0 * R1 * R2)); }
+    static constexpr int n = R0 * R1 * R2 * R3;
+};
+
+// Entries of the twiddle table of pass s (s >= 1): (R-1) * NS, laid out [i-1][m].
+template <class RD> constexpr int tw_pass_elems(int s) { return (RD::r[s] - 1) * RD::ns(s); }
+template <class RD> constexpr int tw_pass_offset(int s)
+{
+    int off = 0;
+    for (int q = 1; q < s; ++q) off += tw_pass_elems<RD>(q);
+    return off;
+}
+
+template <int TX> __device__ __forceinline__ void exchange_sync()
+{
+    if constexpr (TX <= 64) {
+        // signal confined to one wave: only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <typename T> struct vec2;
+template <> struct vec2<float> { using type = float2; };
+template <> struct vec2<double> { using type = double2; };
+
+// Register-resident twiddles: entries pass s occupies, and where they start.
+template <class RD, int TX, int P> constexpr int twreg_pass_count(int s)
+{
+    return s == 0 ? 0 : ((RD::ns(s) <= TX) ? 1 : P / RD::r[s]) * (RD::r[s] - 1);
+}
+template <class RD, int TX, int P> constexpr int twreg_pass_offset(int s)
+{
+    int off = 0;
+    for (int q = 1; q < s; ++q) off += twreg_pass_count<RD, TX, P>(q);
+    return off;
+}
+
+// One Stockham pass on the registers of one thread; leaves v[u + U*q] = output q
+// of butterfly u.
+template <typename T, class RD, int S, int P, int TX, bool TWREG>
+__device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* __restrict__ tw,
+                                             const cx<T>* twr)
+{
+    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    constexpr int twr_pos = twreg_pass_offset<RD, TX, P>(S);
+    if constexpr (S > 0) {
+        constexpr int off = tw_pass_offset<RD>(S);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = (t + TX * u) % NS;
+#pragma unroll
+            for (int i = 1; i < R; ++i) {
+                cx<T> w;
+                if constexpr (TWREG) {
+                    // register copy: one set per thread when m does not depend on u
+                    w = twr[twr_pos + ((NS <= TX) ? 0 : u * (R - 1)) + (i - 1)];
+                } else {
+                    w = tw[off + (i - 1) * NS + m];
+                }
+                v[u + U * i] = cmul(v[u + U * i], w);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) dft_strided<T, R, U>(&v[u]);
+}
+
+// Scatter the pass outputs into LDS in Stockham order and gather the next
+// pass' inputs (positions t + TX*e).
+template <typename T, class RD, int S, int P, int TX, int PADSHIFT>
+__device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
+{
+    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    if constexpr (TX > 64) __syncthreads();   // everyone has finished reading the previous contents
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + TX * u;
+        const int base = (j / NS) * (NS * R) + (j % NS);
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q];
+    }
+    exchange_sync<TX>();
+#pragma unroll
+    for (int e = 0; e < P; ++e) v[e] = lds[lds_pad<PADSHIFT>(t + TX * e)];
+}
+
+// Copy the twiddles pass S needs for this thread into its register array.
+template <typename T, class RD, int S, int P, int TX>
+__device__ __forceinline__ void preload_twiddles(cx<T>* twr, int t, const cx<T>* __restrict__ tw)
+{
+    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    constexpr int off = tw_pass_offset<RD>(S);
+    constexpr int pos = twreg_pass_offset<RD, TX, P>(S);
+    constexpr int sets = (NS <= TX) ? 1 : U;
+#pragma unroll
+    for (int u = 0; u < sets; ++u) {
+        const int m = (t + TX * u) % NS;
+#pragma unroll
+        for (int i = 1; i < R; ++i) twr[pos + u * (R - 1) + (i - 1)] = tw[off + (i - 1) * NS + m];
+    }
+}
+
+template <class RD, int TX, int P> constexpr int twreg_count()
+{
+    int c = 0;
+    for (int s = 1; s < RD::npass; ++s) {
+        const int R = RD::r[s], U = P / R, NS = RD::ns(s);
+        c += ((NS <= TX) ? 1 : U) * (R - 1);
+    }
+    return c;
+}
+
+template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
+__global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
+{
+    using C = cx<T>;
+    constexpr int N = RD::n;
+    constexpr int TX = N / P;
+    constexpr int SLOTS = BLOCK / TX;
+    constexpr int NPASS = RD::npass;
+    constexpr int LDS_ELEMS = ((lds_pad<PADSHIFT>(N - 1) + 1 + 1) / 2) * 2;   // keep slots 16-byte aligned
+    constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER);
+    constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
+    constexpr int TWN = twreg_count<RD, TX, P>();
+    constexpr bool TWREG = (TWN > 0 && TWN <= 18 && !GENERAL);
+    static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int slot = threadIdx.x / TX;
+    const int t = threadIdx.x % TX;
+    C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
+
+    // ---- per-lane constants, fetched once ---------------------------------
+    T wreg[(VAR == V_HANN_POWER) ? P : 1];
+    if constexpr (VAR == V_HANN_POWER) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) wreg[e] = a.win[t + TX * e];
+    }
+    C twr[TWREG ? TWN : 1];
+    if constexpr (TWREG) {
+        if constexpr (NPASS > 1) preload_twiddles<T, RD, 1, P, TX>(twr, t, a.tw);
+        if constexpr (NPASS > 2) preload_twiddles<T, RD, 2, P, TX>(twr, t, a.tw);
+        if constexpr (NPASS > 3) preload_twiddles<T, RD, 3, P, TX>(twr, t, a.tw);
+    }
+
+    const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t b = g * SLOTS + slot;
+        const bool active = b < a.batch;
+        C v[P];
+
+        // ---- load (pass-0 inputs: positions t + TX*e) ----------------------
+        if constexpr (!GENERAL) {
+            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + b * a.in_stride;
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = src[t + TX * e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = C{0, 0};
+            }
+            if constexpr (VAR == V_HANN_POWER) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { v[e].x *= wreg[e]; v[e].y *= wreg[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int j = t + TX * e;
+                C x{0, 0};
+                if (active && j < a.n_in) {
+                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[b * a.in_stride + j];
+                    else x = reinterpret_cast<const C*>(a.in)[b * a.in_stride + j];
+                    if (a.conj_in) x.y = -x.y;
+                    if (a.win) { const T w = a.win[j]; x.x *= w; x.y *= w; }
+                    if (a.pre) x = cmul(x, a.pre[j]);
+                }
+                v[e] = x;
+            }
+        }
+
+        // ---- passes ---------------------------------------------------------
+        pass_compute<T, RD, 0, P, TX, TWREG>(v, t, a.tw, twr);
+        if constexpr (NPASS > 1) {
+            pass_exchange<T, RD, 0, P, TX, PADSHIFT>(v, t, lds);
+            pass_compute<T, RD, 1, P, TX, TWREG>(v, t, a.tw, twr);
+        }
+        if constexpr (NPASS > 2) {
+            pass_exchange<T, RD, 1, P, TX, PADSHIFT>(v, t, lds);
+            pass_compute<T, RD, 2, P, TX, TWREG>(v, t, a.tw, twr);
+        }
+        if constexpr (NPASS > 3) {
+            pass_exchange<T, RD, 2, P, TX, PADSHIFT>(v, t, lds);
+            pass_compute<T, RD, 3, P, TX, TWREG>(v, t, a.tw, twr);
+        }
+
+        // ---- store: output k = t + TX*e sits in v[e] --------------------------
+        if constexpr (POWER) {
+            T* __restrict__ dst = reinterpret_cast<T*>(a.out) + b * a.out_stride;
+            T s[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                C o{v[e].x * a.scale, v[e].y * a.scale};
+                if constexpr (GENERAL) {
+                    const int k = t + TX * e;
+                    if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);   // |.|^2 ignores conj_out
+                }
+                s[e] = o.x * o.x + o.y * o.y;
+            }
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    if constexpr (GENERAL) { if (t + TX * e < a.n_out) dst[t + TX * e] = s[e]; }
+                    else dst[t + TX * e] = s[e];
+                }
+            }
+            if constexpr (VAR == V_GEN_POWER) {
+                if (a.stats != nullptr) {
+                    double mx = 0.0, sm = 0.0, sk = 0.0;
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
+                        const int k = t + TX * e;
+                        const double f = (k < (a.n_out + 1) / 2) ? (double)k : (double)(k - a.n_out);
+                        const double sv = (active && k < a.n_out) ? (double)s[e] : 0.0;
+                        mx = sv > mx ? sv : mx;
+                        sm += sv;
+                        sk += f * sv;
+                    }
+                    constexpr int W = TX < 64 ? TX : 64;
+#pragma unroll
+                    for (int o = W / 2; o > 0; o >>= 1) {
+                        const double omx = __shfl_xor(mx, o, 64);
+                        mx = omx > mx ? omx : mx;
+                        sm += __shfl_xor(sm, o, 64);
+                        sk += __shfl_xor(sk, o, 64);
+                    }
+                    if (active && (t % W) == 0) {
+                        double* st = a.stats + 3 * b;
+                        atomicMax(reinterpret_cast<unsigned long long*>(st),
+                                  (unsigned long long)__double_as_longlong(mx));
+                        atomicAdd(st + 1, sm);
+                        atomicAdd(st + 2, sk);
+                    }
+                }
+            }
+        } else {
+            C* __restrict__ dst = reinterpret_cast<C*>(a.out) + b * a.out_stride;
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    C o{v[e].x * a.scale, v[e].y * a.scale};
+                    if constexpr (GENERAL) {
+                        const int k = t + TX * e;
+                        if (a.conj_out) o.y = -o.y;
+                        if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
+                        if (k < a.n_out) dst[k] = o;
+                    } else {
+                        dst[t + TX * e] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Size table: P points per thread and the pass radices for each 2^k.
+// ---------------------------------------------------------------------------
+template <int LOG2N> struct SizeCfg;
+template <> struct SizeCfg<1>  { static constexpr int P = 2;  using RD = Radices<2, 1, 1, 1>; };
+template <> struct SizeCfg<2>  { static constexpr int P = 4;  using RD = Radices<4, 1, 1, 1>; };
+template <> struct SizeCfg<3>  { static constexpr int P = 8;  using RD = Radices<8, 1, 1, 1>; };
+template <> struct SizeCfg<4>  { static constexpr int P = 4;  using RD = Radices<4, 4, 1, 1>; };
+template <> struct SizeCfg<5>  { static constexpr int P = 8;  using RD = Radices<4, 8, 1, 1>; };
+template <> struct SizeCfg<6>  { static constexpr int P = 8;  using RD = Radices<8, 8, 1, 1>; };
+template <> struct SizeCfg<7>  { static constexpr int P = 16; using RD = Radices<8, 16, 1, 1>; };
+template <> struct SizeCfg<8>  { static constexpr int P = 16; using RD = Radices<16, 16, 1, 1>; };
+template <> struct SizeCfg<9>  { static constexpr int P = 16; using RD = Radices<2, 16, 16, 1>; };
+template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices<16, 4, 16, 1>; };
+template <> struct SizeCfg<11> { static constexpr int P = 16; using RD = Radices<8, 16, 16, 1>; };
+template <> struct SizeCfg<12> { static constexpr int P = 16; using RD = Radices<16, 16, 16, 1>; };
+template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices<2, 16, 16, 16>; };
+template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices<4, 16, 16, 16>; };
+
+constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_write_b64 scatter
+
+template <int LOG2N> struct BlockCfg {
+    static constexpr int TX = (1 << LOG2N) / SizeCfg<LOG2N>::P;
+    static constexpr int BLOCK = TX > 256 ? TX : 256;
+};
+
+template <typename T, int LOG2N> constexpr size_t lds_bytes_for()
+{
+    constexpr int N = 1 << LOG2N;
+    constexpr int TX = BlockCfg<LOG2N>::TX, BLOCK = BlockCfg<LOG2N>::BLOCK;
+    constexpr int SLOTS = BLOCK / TX;
+    constexpr int LDS_ELEMS = ((lds_pad<kPadShift>(N - 1) + 1 + 1) / 2) * 2;
+    return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>);
+}
+
+int pick_grid(const void* kernel, int block, size_t lds, int64_t groups);
+
+template <typename T, int LOG2N, int VAR>
+int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
+{
+    using SC = SizeCfg<LOG2N>;
+    constexpr int BLOCK = BlockCfg<LOG2N>::BLOCK;
+    constexpr int SLOTS = BLOCK / BlockCfg<LOG2N>::TX;
+    constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N>() : 0;
+    auto kern = fft_lds_kernel<T, SC::P, typename SC::RD, kPadShift, BLOCK, VAR>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    MFFT_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_dev = dev;
+    }
+    const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
+    if (groups <= 0) return MFFT_OK;
+    if (grid <= 0) grid = pick_grid(reinterpret_cast<const void*>(kern), BLOCK, lds, groups);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+template <typename T, int LOG2N>
+int launch_variant(int variant, const KArgs<T>& a, int grid, hipStream_t s)
+{
+    switch (variant) {
+    case V_PLAIN: return launch_one<T, LOG2N, V_PLAIN>(a, grid, s);
+    case V_HANN_POWER: return launch_one<T, LOG2N, V_HANN_POWER>(a, grid, s);
+    case V_GEN_CPLX: return launch_one<T, LOG2N, V_GEN_CPLX>(a, grid, s);
+    case V_GEN_POWER: return launch_one<T, LOG2N, V_GEN_POWER>(a, grid, s);
+    }
+    set_error("unknown kernel variant");
+    return MFFT_E_INVALID;
+}
+
+template <typename T, int MAXLOG>
+int launch_lds_any(int log2n, int variant, const KArgs<T>& a, int grid, hipStream_t s)
+{
+    switch (log2n) {
+#define MFFT_CASE(L) case L: if constexpr (L <= MAXLOG) return launch_variant<T, L>(variant, a, grid, s); else break;
+        MFFT_CASE(1) MFFT_CASE(2) MFFT_CASE(3) MFFT_CASE(4) MFFT_CASE(5) MFFT_CASE(6) MFFT_CASE(7)
+        MFFT_CASE(8) MFFT_CASE(9) MFFT_CASE(10) MFFT_CASE(11) MFFT_CASE(12) MFFT_CASE(13) MFFT_CASE(14)
+#undef MFFT_CASE
+    }
+    set_error("length not served by the single-kernel path");
+    return MFFT_E_UNSUPPORTED;
+}
+
+}  // namespace mfft

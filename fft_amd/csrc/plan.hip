@@ -1,0 +1,539 @@
+// Host side of libmfft.so: the C ABI declared in include/mfft.h, plan
+// construction (twiddle / window tables, workspace) and the small element-wise
+// kernels that surround the transform.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "common.h"
+
+namespace mfft {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+    return e == hipErrorOutOfMemory ? MFFT_E_NOMEM : MFFT_E_HIP;
+}
+
+// ---------------------------------------------------------------------------
+// exact-reduction roots of unity
+// ---------------------------------------------------------------------------
+void unit_root(int64_t k, int64_t n, long double* re, long double* im)
+{
+    static const long double two_pi = 6.283185307179586476925286766559005768L;
+    k %= n;
+    if (k < 0) k += n;
+    const __int128 k4 = (__int128)4 * k;
+    const int64_t q = (int64_t)((k4 + n / 2) / n);          // nearest quarter turn
+    const int64_t rem = (int64_t)(k4 - (__int128)q * n);    // |rem| <= n/2
+    const long double a = two_pi * (long double)rem / (4.0L * (long double)n);
+    const long double ca = cosl(a), sa = sinl(a);
+    long double c, s;
+    switch (q & 3) {
+    case 0: c = ca; s = sa; break;
+    case 1: c = -sa; s = ca; break;
+    case 2: c = -ca; s = -sa; break;
+    default: c = sa; s = -ca; break;
+    }
+    *re = c;
+    *im = -s;   // exp(-i*theta)
+}
+
+void build_lds_twiddles(const LdsGeometry& g, std::vector<long double>* re, std::vector<long double>* im)
+{
+    re->clear();
+    im->clear();
+    int ns = 1;
+    for (int s = 0; s < g.npass; ++s) {
+        const int r = g.radix[s];
+        if (s > 0) {
+            for (int i = 1; i < r; ++i)
+                for (int m = 0; m < ns; ++m) {
+                    long double c, d;
+                    unit_root((int64_t)m * i, (int64_t)ns * r, &c, &d);
+                    re->push_back(c);
+                    im->push_back(d);
+                }
+        }
+        ns *= r;
+    }
+}
+
+int device_cu_count()
+{
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        cached = p.multiProcessorCount;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+int pick_grid(const void* kernel, int block, size_t lds, int64_t groups)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    int64_t g = (int64_t)per_cu * device_cu_count();
+    if (g > groups) g = groups;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+
+// pre[j] = win[j] * exp(+i*mu*(t0 + j*dt)) * extra[j]   (win / extra optional)
+template <typename T>
+__global__ void premul_kernel(cx<T>* pre, const T* win, const cx<T>* extra, int n, double mu, double t0,
+                              double dt, int demod)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double re = 1.0, im = 0.0;
+    if (demod) {
+        double s, c;
+        sincos(mu * (t0 + (double)j * dt), &s, &c);
+        re = c;
+        im = s;
+    }
+    if (win) { re *= (double)win[j]; im *= (double)win[j]; }
+    if (extra) {
+        const double er = (double)extra[j].x, ei = (double)extra[j].y;
+        const double r2 = re * er - im * ei, i2 = re * ei + im * er;
+        re = r2;
+        im = i2;
+    }
+    pre[j] = cx<T>{(T)re, (T)im};
+}
+
+template <typename T>
+__global__ void normalize_kernel(const T* in, T* out, int64_t count, const double* d_max)
+{
+    const double m = *d_max;
+    const T den = (T)(m > 0.0 ? m : 1.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] / den;
+}
+
+// out[b][c][r] = in[b][r][c], 32x32 tiles through LDS (33-wide rows: no bank conflicts)
+template <typename T>
+__global__ void transpose_kernel(const cx<T>* in, cx<T>* out, int64_t rows, int64_t cols)
+{
+    __shared__ cx<T> tile[32][33];
+    const int64_t b = blockIdx.z;
+    const cx<T>* src = in + b * rows * cols;
+    cx<T>* dst = out + b * rows * cols;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[i][tx] = src[r * cols + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[c * rows + r] = tile[tx][i];
+    }
+}
+
+// x[r][c] *= exp(-2*pi*i*(r0+r)*(c0+c)/n): two-level table product, tables built on the host
+template <typename T>
+__global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
+                                    int64_t n, const cx<double>* lo, const cx<double>* hi, int lo_bits)
+{
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        // indices are reduced mod n first, and n <= 2^31, so the product fits 64 bits
+        const uint64_t prod = ((uint64_t)(r0 + r) % (uint64_t)n) * ((uint64_t)(c0 + c) % (uint64_t)n);
+        const int64_t k = (int64_t)(prod % (uint64_t)n);
+        const cx<double> a = lo[k & ((int64_t(1) << lo_bits) - 1)], b = hi[k >> lo_bits];
+        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        const cx<T> v = x[i];
+        x[i] = cx<T>{(T)((double)v.x * wr - (double)v.y * wi), (T)((double)v.x * wi + (double)v.y * wr)};
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct Plan {
+    int64_t n = 0, n_in = 0, batch = 0;
+    int dtype = 0;
+    uint32_t flags = 0;
+    int device = 0;
+    int log2n = 0;
+    LdsGeometry geo{};
+    void* d_tw = nullptr;    // LDS-kernel twiddles
+    void* d_win = nullptr;   // real window, n_in samples (MFFT_HANN)
+    void* d_pre = nullptr;   // complex premultiplier, n_in samples (MFFT_DEMOD)
+    // staging for mfft_exec_host
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    double* d_stats = nullptr;
+    int64_t workspace = 0;
+    int launches = 1;
+    std::mutex mu;
+};
+
+static size_t real_size(int dtype) { return dtype == MFFT_C64 ? sizeof(float) : sizeof(double); }
+
+template <typename T>
+static int upload_complex(const std::vector<long double>& re, const std::vector<long double>& im, void** d)
+{
+    std::vector<cx<T>> h(re.size());
+    for (size_t i = 0; i < re.size(); ++i) h[i] = cx<T>{(T)re[i], (T)im[i]};
+    const size_t bytes = (h.empty() ? 1 : h.size()) * sizeof(cx<T>);
+    MFFT_HIP(hipMalloc(d, bytes));
+    if (!h.empty()) MFFT_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    return MFFT_OK;
+}
+
+// symmetric Hann window of m samples, np.hanning's formula, evaluated in long double
+static void hann_window(int64_t m, std::vector<long double>* w)
+{
+    static const long double pi = 3.141592653589793238462643383279502884L;
+    w->resize((size_t)m);
+    if (m == 1) { (*w)[0] = 1.0L; return; }
+    for (int64_t j = 0; j < m; ++j)
+        (*w)[(size_t)j] = 0.5L + 0.5L * cosl(pi * (long double)(2 * j - m + 1) / (long double)(m - 1));
+    (*w)[0] = 0.0L;
+    (*w)[(size_t)m - 1] = 0.0L;
+}
+
+template <typename T> static int upload_real(const std::vector<long double>& v, void** d)
+{
+    std::vector<T> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = (T)v[i];
+    MFFT_HIP(hipMalloc(d, (h.empty() ? 1 : h.size()) * sizeof(T)));
+    if (!h.empty()) MFFT_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MFFT_OK;
+}
+
+static void plan_free(Plan* p)
+{
+    if (!p) return;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(p->device);
+    for (void* q : {p->d_tw, p->d_win, p->d_pre, p->d_in, p->d_out, (void*)p->d_stats})
+        if (q) (void)hipFree(q);
+    if (have_prev) (void)hipSetDevice(prev);
+    delete p;
+}
+
+static int plan_build(Plan* p)
+{
+    if (!is_pow2(p->n)) {
+        set_error("only power-of-two lengths are implemented in this build step");
+        return MFFT_E_UNSUPPORTED;
+    }
+    p->log2n = ilog2(p->n);
+    if (p->n == 1 || !lds_geometry(p->dtype, p->log2n, &p->geo)) {
+        set_error("length outside the single-kernel range");
+        return MFFT_E_UNSUPPORTED;
+    }
+    std::vector<long double> re, im;
+    build_lds_twiddles(p->geo, &re, &im);
+    int rc = p->dtype == MFFT_C64 ? upload_complex<float>(re, im, &p->d_tw)
+                                  : upload_complex<double>(re, im, &p->d_tw);
+    if (rc) return rc;
+    p->workspace += (int64_t)re.size() * 2 * (int64_t)real_size(p->dtype);
+    if (p->flags & MFFT_HANN) {
+        std::vector<long double> w;
+        hann_window(p->n_in, &w);
+        rc = p->dtype == MFFT_C64 ? upload_real<float>(w, &p->d_win) : upload_real<double>(w, &p->d_win);
+        if (rc) return rc;
+        p->workspace += p->n_in * (int64_t)real_size(p->dtype);
+    }
+    if (p->flags & MFFT_DEMOD) {
+        MFFT_HIP(hipMalloc(&p->d_pre, (size_t)p->n_in * 2 * real_size(p->dtype)));
+        p->workspace += p->n_in * 2 * (int64_t)real_size(p->dtype);
+        p->launches += 1;
+    }
+    return MFFT_OK;
+}
+
+template <typename T>
+static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
+                      double* d_stats, hipStream_t s)
+{
+    KArgs<T> a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.tw = static_cast<const cx<T>*>(p->d_tw);
+    a.win = static_cast<const T*>(p->d_win);
+    a.pre = nullptr;
+    a.post = nullptr;
+    a.stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
+    a.batch = p->batch;
+    a.in_stride = p->n_in;
+    a.out_stride = p->n;
+    a.n_in = (int)p->n_in;
+    a.n_out = (int)p->n;
+    a.real_in = (p->flags & MFFT_REAL_IN) ? 1 : 0;
+    a.conj_in = (p->flags & MFFT_INVERSE) ? 1 : 0;
+    a.conj_out = (p->flags & MFFT_INVERSE) ? 1 : 0;
+    a.scale = (T)scale;
+
+    if (p->flags & MFFT_DEMOD) {
+        const int n = (int)p->n_in;
+        hipLaunchKernelGGL(premul_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s,
+                           static_cast<cx<T>*>(p->d_pre), static_cast<const T*>(p->d_win),
+                           (const cx<T>*)nullptr, n, mu, t0, dt, 1);
+        MFFT_HIP(hipGetLastError());
+        a.pre = static_cast<const cx<T>*>(p->d_pre);
+        a.win = nullptr;   // folded into pre
+    }
+    if (a.stats) MFFT_HIP(hipMemsetAsync(a.stats, 0, sizeof(double) * 3 * (size_t)p->batch, s));
+
+    const bool power = (p->flags & MFFT_POWER) != 0;
+    const uint32_t prologue = p->flags & (MFFT_DEMOD | MFFT_REAL_IN | MFFT_INVERSE);
+    const bool full = p->n_in == p->n;
+    int variant;
+    if (power && (p->flags & MFFT_HANN) && !prologue && full && !a.stats) variant = V_HANN_POWER;
+    else if (!power && !(p->flags & MFFT_HANN) && !prologue && full) variant = V_PLAIN;
+    else variant = power ? V_GEN_POWER : V_GEN_CPLX;
+
+    if constexpr (sizeof(T) == 4) return launch_lds_c64(p->log2n, variant, a, 0, s);
+    else return launch_lds_c128(p->log2n, variant, a, 0, s);
+}
+
+static int plan_exec(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
+                     double* d_stats, hipStream_t s)
+{
+    if ((p->flags & MFFT_STATS) && !(p->flags & MFFT_POWER)) {
+        set_error("MFFT_STATS needs MFFT_POWER");
+        return MFFT_E_INVALID;
+    }
+    return p->dtype == MFFT_C64 ? exec_typed<float>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s)
+                                : exec_typed<double>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
+}
+
+// RAII: make the plan's device current for the duration of a call
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace mfft
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace mfft;
+
+extern "C" {
+
+int mfft_version(void) { return 100; }
+
+int mfft_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible");
+        return MFFT_E_NODEVICE;
+    }
+    return n;
+}
+
+const char* mfft_strerror(int code)
+{
+    switch (code) {
+    case MFFT_OK: return "success";
+    case MFFT_E_INVALID: return "invalid argument";
+    case MFFT_E_UNSUPPORTED: return "unsupported request";
+    case MFFT_E_NOMEM: return "out of memory";
+    case MFFT_E_HIP: return "HIP runtime error";
+    case MFFT_E_NODEVICE: return "no usable device";
+    }
+    return "unknown error";
+}
+
+const char* mfft_last_error(void) { return g_err.c_str(); }
+
+int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags)
+{
+    if (!out) { set_error("null plan pointer"); return MFFT_E_INVALID; }
+    *out = nullptr;
+    if (n < 1) { set_error("Invalid number of FFT data points (" + std::to_string(n) + ") specified."); return MFFT_E_INVALID; }
+    if (n_in < 1 || n_in > n) { set_error("n_in must satisfy 1 <= n_in <= n"); return MFFT_E_INVALID; }
+    if (batch < 1) { set_error("batch must be >= 1"); return MFFT_E_INVALID; }
+    if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("dtype must be MFFT_C64 or MFFT_C128"); return MFFT_E_INVALID; }
+    const uint32_t known = MFFT_HANN | MFFT_POWER | MFFT_DEMOD | MFFT_REAL_IN | MFFT_STATS | MFFT_INVERSE;
+    if (flags & ~known) { set_error("unknown flag bits"); return MFFT_E_INVALID; }
+    if ((flags & MFFT_STATS) && !(flags & MFFT_POWER)) { set_error("MFFT_STATS needs MFFT_POWER"); return MFFT_E_INVALID; }
+    if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
+    Plan* p = new (std::nothrow) Plan;
+    if (!p) { set_error("host allocation failed"); return MFFT_E_NOMEM; }
+    p->n = n; p->n_in = n_in; p->batch = batch; p->dtype = dtype; p->flags = flags;
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("hipGetDevice failed"); return MFFT_E_HIP; }
+    const int rc = plan_build(p);
+    if (rc != MFFT_OK) { plan_free(p); return rc; }
+    *out = reinterpret_cast<mfft_plan>(p);
+    return MFFT_OK;
+}
+
+int mfft_plan_destroy(mfft_plan plan)
+{
+    if (!plan) return MFFT_OK;
+    plan_free(reinterpret_cast<Plan*>(plan));
+    return MFFT_OK;
+}
+
+int mfft_plan_workspace_bytes(mfft_plan plan, int64_t* bytes)
+{
+    if (!plan || !bytes) { set_error("null argument"); return MFFT_E_INVALID; }
+    *bytes = reinterpret_cast<Plan*>(plan)->workspace;
+    return MFFT_OK;
+}
+
+int mfft_plan_launches(mfft_plan plan, int* launches)
+{
+    if (!plan || !launches) { set_error("null argument"); return MFFT_E_INVALID; }
+    *launches = reinterpret_cast<Plan*>(plan)->launches;
+    return MFFT_OK;
+}
+
+int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
+              double* d_stats, void* stream)
+{
+    if (!plan || !d_in || !d_out) { set_error("null argument"); return MFFT_E_INVALID; }
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    if ((p->flags & MFFT_STATS) && !d_stats) { set_error("plan has MFFT_STATS but d_stats is null"); return MFFT_E_INVALID; }
+    DeviceGuard g(p->device);
+    if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
+    return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, static_cast<hipStream_t>(stream));
+}
+
+int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu, double t0,
+                   double dt, double* h_stats)
+{
+    if (!plan || !h_in || !h_out) { set_error("null argument"); return MFFT_E_INVALID; }
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    if ((p->flags & MFFT_STATS) && !h_stats) { set_error("plan has MFFT_STATS but h_stats is null"); return MFFT_E_INVALID; }
+    DeviceGuard g(p->device);
+    if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
+    std::lock_guard<std::mutex> lock(p->mu);
+    const size_t rs = real_size(p->dtype);
+    const size_t in_bytes = (size_t)p->batch * (size_t)p->n_in * rs * ((p->flags & MFFT_REAL_IN) ? 1 : 2);
+    const size_t out_bytes = (size_t)p->batch * (size_t)p->n * rs * ((p->flags & MFFT_POWER) ? 1 : 2);
+    if (!p->d_in) MFFT_HIP(hipMalloc(&p->d_in, in_bytes));
+    if (!p->d_out) MFFT_HIP(hipMalloc(&p->d_out, out_bytes));
+    if ((p->flags & MFFT_STATS) && !p->d_stats)
+        MFFT_HIP(hipMalloc((void**)&p->d_stats, sizeof(double) * 3 * (size_t)p->batch));
+    MFFT_HIP(hipMemcpy(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice));
+    const int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
+    if (rc != MFFT_OK) return rc;
+    MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
+    if (p->flags & MFFT_STATS)
+        MFFT_HIP(hipMemcpy(h_stats, p->d_stats, sizeof(double) * 3 * (size_t)p->batch, hipMemcpyDeviceToHost));
+    return MFFT_OK;
+}
+
+int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const double* d_max, int dtype,
+                          void* stream)
+{
+    if (!d_in || !d_out || !d_max || count < 0) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (count == 0) return MFFT_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == MFFT_C64)
+        hipLaunchKernelGGL(normalize_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const float*>(d_in), static_cast<float*>(d_out), count, d_max);
+    else if (dtype == MFFT_C128)
+        hipLaunchKernelGGL(normalize_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const double*>(d_in), static_cast<double*>(d_out), count, d_max);
+    else { set_error("bad dtype"); return MFFT_E_INVALID; }
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, int64_t batch, int dtype,
+                   void* stream)
+{
+    if (!d_in || !d_out || rows < 1 || cols < 1 || batch < 1 || d_in == d_out) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (batch > 65535 || (rows + 31) / 32 > 65535) { set_error("transpose grid too large"); return MFFT_E_UNSUPPORTED; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+    if (dtype == MFFT_C64)
+        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, static_cast<const cx<float>*>(d_in),
+                           static_cast<cx<float>*>(d_out), rows, cols);
+    else if (dtype == MFFT_C128)
+        hipLaunchKernelGGL(transpose_kernel<double>, grid, dim3(256), 0, s, static_cast<const cx<double>*>(d_in),
+                           static_cast<cx<double>*>(d_out), rows, cols);
+    else { set_error("bad dtype"); return MFFT_E_INVALID; }
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t c0, int64_t n_total,
+                      int dtype, void* stream)
+{
+    if (!d_x || rows < 1 || cols < 1 || r0 < 0 || c0 < 0 || n_total < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (n_total > (int64_t(1) << 31)) { set_error("n_total above 2^31"); return MFFT_E_UNSUPPORTED; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // two-level table: k = hi * 2^lo_bits + lo
+    const int total_bits = ilog2(n_total);
+    const int lo_bits = total_bits / 2;
+    const int64_t lo_n = int64_t(1) << lo_bits;
+    const int64_t hi_n = (n_total + lo_n - 1) / lo_n;
+    std::vector<cx<double>> h((size_t)(lo_n + hi_n));
+    for (int64_t k = 0; k < lo_n; ++k) {
+        long double c, d;
+        unit_root(k, n_total, &c, &d);
+        h[(size_t)k] = cx<double>{(double)c, (double)d};
+    }
+    for (int64_t k = 0; k < hi_n; ++k) {
+        long double c, d;
+        unit_root(k * lo_n, n_total, &c, &d);
+        h[(size_t)(lo_n + k)] = cx<double>{(double)c, (double)d};
+    }
+    cx<double>* d_tab = nullptr;
+    MFFT_HIP(hipMalloc((void**)&d_tab, h.size() * sizeof(cx<double>)));
+    hipError_t e = hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(cx<double>), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { (void)hipFree(d_tab); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == MFFT_C64)
+        hipLaunchKernelGGL(twiddle_tile_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<cx<float>*>(d_x), rows, cols, r0, c0, n_total, d_tab, d_tab + lo_n, lo_bits);
+    else if (dtype == MFFT_C128)
+        hipLaunchKernelGGL(twiddle_tile_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<cx<double>*>(d_x), rows, cols, r0, c0, n_total, d_tab, d_tab + lo_n, lo_bits);
+    else { (void)hipFree(d_tab); set_error("bad dtype"); return MFFT_E_INVALID; }
+    e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(s);   // the table is a temporary of this call
+    (void)hipFree(d_tab);
+    if (e != hipSuccess) return hip_fail(e, "twiddle_tile_kernel", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    return MFFT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""Plans over libmfft.so: thin, allocation-free wrappers around the C ABI.
+
+``Plan`` is the Python face of ``mfft_plan_1d``.  Buffers are passed either as
+integers (device addresses), as objects exposing ``data_ptr()`` (torch tensors:
+torch is used by callers only to own device memory and streams), or -- through
+``exec_host`` -- as numpy arrays that the library copies in and out itself.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+
+def _addr(buf) -> int:
+    if buf is None:
+        return 0
+    if isinstance(buf, int):
+        return buf
+    if hasattr(buf, "data_ptr"):
+        return int(buf.data_ptr())
+    raise TypeError(f"cannot take a device address from {type(buf).__name__}")
+
+
+class Plan:
+    """One batched 1-D transform configuration (see include/mfft.h: mfft_plan_1d)."""
+
+    def __init__(self, n: int, n_in: int | None = None, batch: int = 1, dtype: int = _lib.C64,
+                 flags: int = 0):
+        lib = _lib.load()
+        self.n = int(n)
+        self.n_in = self.n if n_in is None else int(n_in)
+        self.batch = int(batch)
+        self.dtype = int(dtype)
+        self.flags = int(flags)
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.mfft_plan_1d(ctypes.byref(self._h), self.n, self.n_in, self.batch,
+                                    self.dtype, self.flags))
+        self._lock = threading.Lock()
+
+    # -- introspection ------------------------------------------------------
+    @property
+    def real_dtype(self):
+        return np.float32 if self.dtype == _lib.C64 else np.float64
+
+    @property
+    def complex_dtype(self):
+        return np.complex64 if self.dtype == _lib.C64 else np.complex128
+
+    @property
+    def in_dtype(self):
+        return self.real_dtype if self.flags & _lib.REAL_IN else self.complex_dtype
+
+    @property
+    def out_dtype(self):
+        return self.real_dtype if self.flags & _lib.POWER else self.complex_dtype
+
+    @property
+    def workspace_bytes(self) -> int:
+        v = ctypes.c_int64()
+        _lib.check(_lib.load().mfft_plan_workspace_bytes(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def launches(self) -> int:
+        v = ctypes.c_int()
+        _lib.check(_lib.load().mfft_plan_launches(self._h, ctypes.byref(v)))
+        return v.value
+
+    # -- execution ------------------------------------------------------------
+    def exec(self, d_in, d_out, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0, dt: float = 1.0,
+             d_stats=None, stream: int = 0):
+        """Asynchronous execution on device buffers (addresses or tensors)."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        _lib.check(_lib.load().mfft_exec(self._h, _addr(d_in), _addr(d_out), float(scale), float(mu),
+                                         float(t0), float(dt), _addr(d_stats), int(stream) or None))
+
+    def exec_host(self, x: np.ndarray, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0,
+                  dt: float = 1.0):
+        """Synchronous execution on a numpy array of shape (batch, n_in) (or (n_in,)
+        when batch == 1).  Returns the output array, plus a (batch, 3) float64 array
+        {max S, sum S, sum f_k S} when the plan has the STATS flag."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        x = np.ascontiguousarray(x, dtype=self.in_dtype)
+        if x.size != self.batch * self.n_in:
+            raise ValueError(f"input has {x.size} elements, plan expects {self.batch}x{self.n_in}")
+        lead = x.shape[:-1] if x.ndim > 1 else ()
+        out = np.empty(lead + (self.n,), dtype=self.out_dtype)
+        stats = np.zeros((self.batch, 3), dtype=np.float64) if self.flags & _lib.STATS else None
+        with self._lock:
+            _lib.check(_lib.load().mfft_exec_host(
+                self._h, x.ctypes.data, out.ctypes.data, float(scale), float(mu), float(t0), float(dt),
+                stats.ctypes.data if stats is not None else None))
+        return (out, stats) if stats is not None else out
+
+    # -- lifetime ---------------------------------------------------------------
+    def destroy(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().mfft_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()

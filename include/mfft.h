@@ -1,0 +1,118 @@
+/*
+ * mfft -- MI355X (gfx950) FFT engine for the spectral hot path: C ABI.
+ *
+ * The reference has no FFI of its own: its seam is the Python call
+ *     F = dt * np.fft.fft(xw, n=Nfft)            final2.py:143
+ *                                                streamlit_app_combined.py:204, :213
+ * surrounded by the window / power / normalise expressions of
+ *     fft_from_timeseries                        final2.py:139-146
+ *     fft_extract_E_p                            streamlit_app_combined.py:199-215
+ * Each entry point below names the reference expression it replaces.  The Python
+ * side (fft_amd/_lib.py) binds these with ctypes; nothing in the signatures is a
+ * torch or numpy type -- plain pointers, sizes and scalars only.
+ *
+ * Conventions: all functions return 0 (MFFT_OK) or a negative MFFT_E_* code and
+ * never throw.  mfft_last_error() returns a thread-local detail string.  Plans
+ * are bound to the HIP device that was current when they were created.  A plan
+ * may be executed from several host threads, but two executions of the SAME plan
+ * must not overlap (they share the plan's workspace); distinct plans are
+ * independent.  "d_" pointers are device memory, "h_" pointers host memory.
+ */
+#ifndef MFFT_H
+#define MFFT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfft_plan_s* mfft_plan;
+
+/* element types: the arithmetic type of the transform */
+#define MFFT_C64   0   /* complex64  (float  re, im) -- fp32 butterflies */
+#define MFFT_C128  1   /* complex128 (double re, im) -- fp64 butterflies */
+
+/* plan flags */
+#define MFFT_HANN     0x01u  /* x[j] *= hann(n_in)[j]      np.hanning(len(f_t)); f_t*win   final2.py:139-140 */
+#define MFFT_POWER    0x02u  /* out = |scale*F|^2 (real)   np.abs(dt*F)**2                 final2.py:143,145 */
+#define MFFT_DEMOD    0x04u  /* x[j] *= exp(+i*mu*(t0+j*dt))                                streamlit_app_combined.py:209 */
+#define MFFT_REAL_IN  0x08u  /* input is real (float/double), promoted like numpy does      BASELINE config 1 */
+#define MFFT_STATS    0x10u  /* also return per-transform max(S), sum(S), sum(f_k*S)        final2.py:146, streamlit_app_combined.py:207 */
+#define MFFT_INVERSE  0x20u  /* exponent +2*pi*i, unnormalised (used internally by the chirp-z path) */
+
+/* error codes */
+#define MFFT_OK              0
+#define MFFT_E_INVALID      -1   /* bad argument (the Python layer raises ValueError) */
+#define MFFT_E_UNSUPPORTED  -2   /* valid request this build cannot serve */
+#define MFFT_E_NOMEM        -3   /* host or device allocation failed */
+#define MFFT_E_HIP          -4   /* a HIP runtime call failed; see mfft_last_error() */
+#define MFFT_E_NODEVICE     -5   /* no usable gfx950 device */
+
+/* ---- library ------------------------------------------------------------- */
+
+int         mfft_version(void);            /* 10000*major + 100*minor + patch */
+int         mfft_device_count(void);       /* number of HIP devices, or MFFT_E_NODEVICE */
+const char* mfft_strerror(int code);
+const char* mfft_last_error(void);
+
+/* ---- 1-D plans -------------------------------------------------------------
+ * Replaces np.fft.fft(x, n=n, axis=-1) on a (batch, n_in) array, fused with the
+ * expressions selected by `flags`:
+ *
+ *   for each of `batch` signals x[0..n_in):
+ *     x[j] *= hann(n_in)[j]                      if MFFT_HANN
+ *     x[j] *= exp(+i*mu*(t0 + j*dt))             if MFFT_DEMOD
+ *     X[k]  = sum_{j<n_in} x[j]*exp(-2*pi*i*j*k/n),  k < n     (zero-padded, n_in <= n)
+ *     out[k] = scale*X[k]                        (complex)      dt*np.fft.fft(...)
+ *        or   = (scale*Re X)^2 + (scale*Im X)^2  (real)         if MFFT_POWER
+ *
+ * n may be any positive length: powers of two run as Stockham radix-16/8/4/2
+ * passes (one LDS-resident kernel up to 16384 points c64 / 8192 c128, a
+ * multi-kernel four-step decomposition above that); other lengths run through a
+ * chirp-z (Bluestein) wrapper around the power-of-two kernels.
+ */
+int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags);
+int mfft_plan_destroy(mfft_plan plan);
+
+/* Bytes of device workspace the plan holds, and the number of kernel launches
+ * one execution issues (for reporting). */
+int mfft_plan_workspace_bytes(mfft_plan plan, int64_t* bytes);
+int mfft_plan_launches(mfft_plan plan, int* launches);
+
+/* Execute on device buffers.  d_in: batch*n_in elements (complex, or real if
+ * MFFT_REAL_IN), contiguous per signal.  d_out: batch*n complex, or batch*n real
+ * if MFFT_POWER.  d_stats: NULL, or (with MFFT_STATS) 3*batch doubles receiving
+ * per signal {max_k S[k], sum_k S[k], sum_k f_k*S[k]} where S is the power
+ * spectrum and f_k = k for k < ceil(n/2), k-n after (np.fft.fftfreq order, in
+ * bins).  mu, t0, dt are read only with MFFT_DEMOD.  stream: a hipStream_t, or
+ * NULL for the default stream.  The call is asynchronous. */
+int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
+              double mu, double t0, double dt, double* d_stats, void* stream);
+
+/* Same transform on host buffers (numpy arrays): copies in, runs, copies out and
+ * synchronises.  h_stats: NULL or 3*batch doubles. */
+int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale,
+                   double mu, double t0, double dt, double* h_stats);
+
+/* ---- element-wise helpers used around the transform ------------------------ */
+
+/* out[k] = in[k] / (m > 0 ? m : 1) with m = *d_max  -- S / (S.max() if S.max() > 0 else 1.0), final2.py:146.
+ * dtype selects float (MFFT_C64) or double (MFFT_C128) real arrays. */
+int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const double* d_max,
+                          int dtype, void* stream);
+
+/* out[b][c][r] = in[b][r][c]  for `batch` matrices of rows x cols complex elements
+ * (local re-layout step of the pencil / four-step decompositions). */
+int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, int64_t batch,
+                   int dtype, void* stream);
+
+/* x[r][c] *= exp(-2*pi*i * (r0 + r)*(c0 + c) / n_total)  on a rows x cols complex tile
+ * (the inter-step twiddle of the four-step algorithm). */
+int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
+                      int64_t n_total, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFFT_H */

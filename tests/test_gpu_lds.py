@@ -1,0 +1,125 @@
+"""GPU parity: the LDS-resident Stockham kernels (through the C ABI) against the
+CPU oracle on the same seeded inputs.  Tolerances are BASELINE.json's: relative
+L2 <= 1e-5 for complex64, <= 1e-12 for complex128, both measured against the
+oracle evaluated in float64."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-5, 1: 1e-12}
+
+
+def _rand(shape, seed, dtype):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fft_amd
+    assert fft_amd.device_count() >= 1
+    return fft_amd
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("log2n", list(range(1, 15)))
+def test_plain_fft_pow2(fa, dtype, log2n):
+    n = 1 << log2n
+    if dtype == 1 and log2n > 13:
+        pytest.skip("complex128 single-kernel range ends at 8192")
+    batch = 7 if n >= 2048 else 37          # ragged against the slots-per-workgroup
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), n + dtype, cdt)
+    with fa.Plan(n, batch=batch, dtype=dtype) as p:
+        y = p.exec_host(x)
+    assert y.dtype == cdt and y.shape == (batch, n)
+    ref = so.dft(x, engine="numpy")
+    assert rel_l2(y, ref) < TOL[dtype]
+    # one row against the plain-C engine as well
+    assert rel_l2(y[0], so.dft(x[0], engine="c")) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n", [64, 1024, 4096])
+def test_hann_power_fused(fa, dtype, n):
+    batch = 33
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), 3 * n + dtype, cdt)
+    dt = 0.01
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.HANN | fa.POWER) as p:
+        S = p.exec_host(x, scale=dt)
+    assert S.dtype == (np.float32 if dtype == 0 else np.float64)
+    _, ref = so.windowed_power(x, use_hann=True, dt=dt, engine="numpy")
+    assert rel_l2(S, ref) < 2 * TOL[dtype]      # |.|^2 doubles the relative error of F
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_zero_pad_window_demod_stats(fa, dtype):
+    n_in, n, batch = 1501, 4096, 3
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n_in), 99 + dtype, cdt)
+    dt, mu = 0.01, 0.37
+    times = np.arange(n_in) * dt
+    flags = fa.HANN | fa.POWER | fa.DEMOD | fa.STATS
+    with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags) as p:
+        S, stats = p.exec_host(x, scale=dt, mu=mu, t0=0.0, dt=dt)
+    _, ref = so.windowed_power(x, n=n, use_hann=True, dt=dt, engine="numpy", mu=mu, times=times)
+    assert rel_l2(S, ref) < 2 * TOL[dtype]
+    f = np.fft.fftfreq(n) * n
+    tol = 1e-5 if dtype == 0 else 1e-11
+    np.testing.assert_allclose(stats[:, 0], ref.max(axis=1), rtol=tol)
+    np.testing.assert_allclose(stats[:, 1], ref.sum(axis=1), rtol=tol)
+    np.testing.assert_allclose(stats[:, 2], (ref * f).sum(axis=1), rtol=0,
+                               atol=tol * np.abs(ref * f).sum(axis=1).max())
+    # complex output of the same prologue
+    with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=fa.HANN | fa.DEMOD) as p:
+        F = p.exec_host(x, scale=dt, mu=mu, t0=0.0, dt=dt)
+    Fref, _ = so.windowed_power(x, n=n, use_hann=True, dt=dt, engine="numpy", mu=mu, times=times)
+    assert rel_l2(F, Fref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_real_input_and_inverse(fa, dtype):
+    n, batch = 4096, 2
+    rdt = np.float32 if dtype == 0 else np.float64
+    rng = np.random.default_rng(5)
+    xr = rng.standard_normal((batch, n)).astype(rdt)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
+        y = p.exec_host(xr)
+    assert rel_l2(y, np.fft.fft(xr.astype(np.float64))) < TOL[dtype]
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), 6, cdt)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.INVERSE) as p:
+        y = p.exec_host(x)
+    assert rel_l2(y, np.fft.ifft(x.astype(np.complex128)) * n) < TOL[dtype]
+
+
+def test_known_answers_on_device(fa):
+    n = 1024
+    imp = np.zeros((1, n), np.complex128); imp[0, 1] = 1.0
+    with fa.Plan(n, dtype=1) as p:
+        y = p.exec_host(imp)
+        assert np.max(np.abs(y[0] - np.exp(-2j * np.pi * np.arange(n) / n))) < 1e-14
+        lin_a = _rand((1, n), 1, np.complex128); lin_b = _rand((1, n), 2, np.complex128)
+        ya, yb, yab = p.exec_host(lin_a), p.exec_host(lin_b), p.exec_host(2 * lin_a - 3j * lin_b)
+        assert rel_l2(yab, 2 * ya - 3j * yb) < 1e-14
+        # Parseval
+        assert abs(np.sum(np.abs(ya) ** 2) - n * np.sum(np.abs(lin_a) ** 2)) < 1e-11 * n * np.sum(np.abs(lin_a) ** 2)
+
+
+def test_argument_errors(fa):
+    with pytest.raises(ValueError):
+        fa.Plan(0)
+    with pytest.raises(ValueError):
+        fa.Plan(16, n_in=32)
+    with pytest.raises(ValueError):
+        fa.Plan(16, batch=0)
+    with pytest.raises(ValueError):
+        fa.Plan(16, flags=fa.STATS)
+    with fa.Plan(16) as p:
+        with pytest.raises(ValueError):
+            p.exec_host(np.zeros(8, np.complex64))
