@@ -35,8 +35,12 @@ DT = 0.01
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle", type=float, default=1.5,
+                    help="seconds of untimed launches before the warmup steps: the GPU needs ~0.1-0.3 s of "
+                         "sustained load after idle before its clocks settle (first launches run 135 us, "
+                         "then up to 185 us, then settle)")
     ap.add_argument("--n", type=int, default=N_POINTS, help="transform length (default: the headline 1024)")
     ap.add_argument("--batch", type=int, default=BATCH, help="signals per GPU (default: the headline 65536)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -108,25 +112,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    # kernel launch durations, measured with events on the launch stream
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # Average launch duration of the (single) kernel of a step: two events on the
+    # launch stream around the K back-to-back launches of the timed region.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record()
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        stops[i].record()
+    ev1.record()
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-    kern_avg_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
+    kern_avg_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
 
     flops_step = 5.0 * n * log2n * batch * world
     alg_bytes = (8 + 4) * n * batch                       # per launch, per GPU
@@ -154,7 +162,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kern_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg_bytes / kern_avg_s / 1e9 / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "fft_lds_kernel (hann+power)",
-                     "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
+                     "kernel_ms_avg": kern_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

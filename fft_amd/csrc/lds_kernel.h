@@ -22,7 +22,70 @@
 #pragma once
 #include "common.h"
 
+// Tuning knobs (overridable with -D for A/B builds; the defaults are the measured best).
+#ifndef MFFT_TW_SRC
+#define MFFT_TW_SRC 1        // fast variants: twiddles from 0 = global (L1/L2), 1 = registers, 2 = LDS table
+#endif
+#ifndef MFFT_WIN_SRC
+#define MFFT_WIN_SRC 0       // hann variant: window from 0 = registers, 1 = LDS table, 2 = global (L1/L2)
+#endif
+#ifndef MFFT_WAVES_PER_EU
+#define MFFT_WAVES_PER_EU 0  // 0 = let the compiler choose; k = cap VGPRs for k waves per SIMD
+#endif
+#ifndef MFFT_BLOCK_MIN
+#define MFFT_BLOCK_MIN 256   // workgroup size when a signal needs fewer threads than this
+#endif
+#ifndef MFFT_NT
+#define MFFT_NT 1            // 1 = non-temporal global loads/stores in the fast variants (+10 % on the 1024-point batch)
+#endif
+#ifndef MFFT_DIAG_NOFFT
+#define MFFT_DIAG_NOFFT 0    // diagnostic builds only: skip the passes (load -> epilogue -> store) to price the memory side
+#endif
+#ifndef MFFT_R1024
+#define MFFT_R1024 16, 4, 16, 1
+#endif
+
 namespace mfft {
+
+enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
+enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2 };
+
+#if MFFT_WAVES_PER_EU > 0
+#define MFFT_LAUNCH_BOUNDS(B) __launch_bounds__(B, MFFT_WAVES_PER_EU)
+#else
+#define MFFT_LAUNCH_BOUNDS(B) __launch_bounds__(B)
+#endif
+
+// Streaming accesses: each input element is read once and each output written once.
+template <typename T> struct nt_vec { using type = T __attribute__((ext_vector_type(2))); };
+template <typename T> __device__ __forceinline__ cx<T> ld_stream(const cx<T>* p)
+{
+#if MFFT_NT
+    using V = typename nt_vec<T>::type;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    return cx<T>{v.x, v.y};
+#else
+    return *p;
+#endif
+}
+template <typename T> __device__ __forceinline__ void st_stream(cx<T>* p, cx<T> v)
+{
+#if MFFT_NT
+    using V = typename nt_vec<T>::type;
+    V w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<V*>(p));
+#else
+    *p = v;
+#endif
+}
+template <typename T> __device__ __forceinline__ void st_stream(T* p, T v)
+{
+#if MFFT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 template <int R0, int R1, int R2, int R3> struct Radices {
     static constexpr int r[4] = {R0, R1, R2, R3};
@@ -70,9 +133,9 @@ template <class RD, int TX, int P> constexpr int twreg_pass_offset(int s)
 
 // One Stockham pass on the registers of one thread; leaves v[u + U*q] = output q
 // of butterfly u.
-template <typename T, class RD, int S, int P, int TX, bool TWREG>
+template <typename T, class RD, int S, int P, int TX, int TWSRC>
 __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* __restrict__ tw,
-                                             const cx<T>* twr)
+                                             const cx<T>* twr, const cx<T>* twl)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
     constexpr int twr_pos = twreg_pass_offset<RD, TX, P>(S);
@@ -84,9 +147,11 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
 #pragma unroll
             for (int i = 1; i < R; ++i) {
                 cx<T> w;
-                if constexpr (TWREG) {
+                if constexpr (TWSRC == TW_REG) {
                     // register copy: one set per thread when m does not depend on u
                     w = twr[twr_pos + ((NS <= TX) ? 0 : u * (R - 1)) + (i - 1)];
+                } else if constexpr (TWSRC == TW_LDS) {
+                    w = twl[off + (i - 1) * NS + m];
                 } else {
                     w = tw[off + (i - 1) * NS + m];
                 }
@@ -143,8 +208,33 @@ template <class RD, int TX, int P> constexpr int twreg_count()
     return c;
 }
 
+template <class RD> constexpr int tw_total_elems()
+{
+    int c = 0;
+    for (int s = 1; s < RD::npass; ++s) c += tw_pass_elems<RD>(s);
+    return c;
+}
+
+// Which source the fast variants take their twiddles / window from, and the LDS
+// bytes the shared tables need behind the data slots.
+template <class RD, int TX, int P, int VAR> constexpr int tw_source()
+{
+    constexpr bool general = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
+    if (general || RD::npass < 2) return TW_GLOBAL;
+    if (MFFT_TW_SRC == TW_REG) return twreg_count<RD, TX, P>() <= 18 ? TW_REG : TW_GLOBAL;
+    if (MFFT_TW_SRC == TW_LDS) return tw_total_elems<RD>() <= 2048 ? TW_LDS : TW_GLOBAL;
+    return TW_GLOBAL;
+}
+template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_lds_bytes()
+{
+    size_t b = 0;
+    if (tw_source<RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
+    if (VAR == V_HANN_POWER && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
+    return b;
+}
+
 template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
-__global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
+__global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
 {
     using C = cx<T>;
     constexpr int N = RD::n;
@@ -155,7 +245,9 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
     constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER);
     constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
     constexpr int TWN = twreg_count<RD, TX, P>();
-    constexpr bool TWREG = (TWN > 0 && TWN <= 18 && !GENERAL);
+    constexpr int TWSRC = tw_source<RD, TX, P, VAR>();
+    constexpr bool TWREG = TWSRC == TW_REG;
+    constexpr int WINSRC = MFFT_WIN_SRC;
     static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -163,9 +255,20 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
     const int t = threadIdx.x % TX;
     C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
 
+    // ---- tables shared by the workgroup, staged in LDS behind the data slots --
+    C* twl = reinterpret_cast<C*>(smem_raw) + (size_t)SLOTS * LDS_ELEMS;
+    T* winl = reinterpret_cast<T*>(twl + (TWSRC == TW_LDS ? tw_total_elems<RD>() : 0));
+    if constexpr (TWSRC == TW_LDS) {
+        for (int i = threadIdx.x; i < tw_total_elems<RD>(); i += BLOCK) twl[i] = a.tw[i];
+    }
+    if constexpr (VAR == V_HANN_POWER && WINSRC == WIN_LDS) {
+        for (int i = threadIdx.x; i < N; i += BLOCK) winl[i] = a.win[i];
+    }
+    if constexpr (TWSRC == TW_LDS || (VAR == V_HANN_POWER && WINSRC == WIN_LDS)) __syncthreads();
+
     // ---- per-lane constants, fetched once ---------------------------------
-    T wreg[(VAR == V_HANN_POWER) ? P : 1];
-    if constexpr (VAR == V_HANN_POWER) {
+    T wreg[(VAR == V_HANN_POWER && WINSRC == WIN_REG) ? P : 1];
+    if constexpr (VAR == V_HANN_POWER && WINSRC == WIN_REG) {
 #pragma unroll
         for (int e = 0; e < P; ++e) wreg[e] = a.win[t + TX * e];
     }
@@ -184,17 +287,21 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
 
         // ---- load (pass-0 inputs: positions t + TX*e) ----------------------
         if constexpr (!GENERAL) {
-            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + b * a.in_stride;
-            if (active) {
+            // a slot beyond the batch re-reads the last signal and skips its stores: no branch here
+            const int64_t bl = active ? b : a.batch - 1;
+            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = src[t + TX * e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = C{0, 0};
-            }
+            for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
             if constexpr (VAR == V_HANN_POWER) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { v[e].x *= wreg[e]; v[e].y *= wreg[e]; }
+                for (int e = 0; e < P; ++e) {
+                    T w;
+                    if constexpr (WINSRC == WIN_REG) w = wreg[e];
+                    else if constexpr (WINSRC == WIN_LDS) w = winl[t + TX * e];
+                    else w = a.win[t + TX * e];
+                    v[e].x *= w;
+                    v[e].y *= w;
+                }
             }
         } else {
 #pragma unroll
@@ -213,19 +320,21 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
         }
 
         // ---- passes ---------------------------------------------------------
-        pass_compute<T, RD, 0, P, TX, TWREG>(v, t, a.tw, twr);
+#if !MFFT_DIAG_NOFFT
+        pass_compute<T, RD, 0, P, TX, TWSRC>(v, t, a.tw, twr, twl);
         if constexpr (NPASS > 1) {
             pass_exchange<T, RD, 0, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 1, P, TX, TWREG>(v, t, a.tw, twr);
+            pass_compute<T, RD, 1, P, TX, TWSRC>(v, t, a.tw, twr, twl);
         }
         if constexpr (NPASS > 2) {
             pass_exchange<T, RD, 1, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 2, P, TX, TWREG>(v, t, a.tw, twr);
+            pass_compute<T, RD, 2, P, TX, TWSRC>(v, t, a.tw, twr, twl);
         }
         if constexpr (NPASS > 3) {
             pass_exchange<T, RD, 2, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 3, P, TX, TWREG>(v, t, a.tw, twr);
+            pass_compute<T, RD, 3, P, TX, TWSRC>(v, t, a.tw, twr, twl);
         }
+#endif
 
         // ---- store: output k = t + TX*e sits in v[e] --------------------------
         if constexpr (POWER) {
@@ -244,7 +353,7 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
                     if constexpr (GENERAL) { if (t + TX * e < a.n_out) dst[t + TX * e] = s[e]; }
-                    else dst[t + TX * e] = s[e];
+                    else st_stream(dst + t + TX * e, s[e]);
                 }
             }
             if constexpr (VAR == V_GEN_POWER) {
@@ -288,7 +397,7 @@ __global__ void __launch_bounds__(BLOCK) fft_lds_kernel(const KArgs<T> a)
                         if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
                         if (k < a.n_out) dst[k] = o;
                     } else {
-                        dst[t + TX * e] = o;
+                        st_stream(dst + t + TX * e, o);
                     }
                 }
             }
@@ -309,7 +418,7 @@ template <> struct SizeCfg<6>  { static constexpr int P = 8;  using RD = Radices
 template <> struct SizeCfg<7>  { static constexpr int P = 16; using RD = Radices<8, 16, 1, 1>; };
 template <> struct SizeCfg<8>  { static constexpr int P = 16; using RD = Radices<16, 16, 1, 1>; };
 template <> struct SizeCfg<9>  { static constexpr int P = 16; using RD = Radices<2, 16, 16, 1>; };
-template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices<16, 4, 16, 1>; };
+template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices<MFFT_R1024>; };
 template <> struct SizeCfg<11> { static constexpr int P = 16; using RD = Radices<8, 16, 16, 1>; };
 template <> struct SizeCfg<12> { static constexpr int P = 16; using RD = Radices<16, 16, 16, 1>; };
 template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices<2, 16, 16, 16>; };
@@ -319,16 +428,17 @@ constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_wri
 
 template <int LOG2N> struct BlockCfg {
     static constexpr int TX = (1 << LOG2N) / SizeCfg<LOG2N>::P;
-    static constexpr int BLOCK = TX > 256 ? TX : 256;
+    static constexpr int BLOCK = TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN;
 };
 
-template <typename T, int LOG2N> constexpr size_t lds_bytes_for()
+template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_for()
 {
+    using SC = SizeCfg<LOG2N>;
     constexpr int N = 1 << LOG2N;
     constexpr int TX = BlockCfg<LOG2N>::TX, BLOCK = BlockCfg<LOG2N>::BLOCK;
     constexpr int SLOTS = BLOCK / TX;
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>(N - 1) + 1 + 1) / 2) * 2;
-    return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>);
+    return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>) + table_lds_bytes<T, typename SC::RD, TX, SC::P, VAR>();
 }
 
 int pick_grid(const void* kernel, int block, size_t lds, int64_t groups);
@@ -339,7 +449,7 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
     using SC = SizeCfg<LOG2N>;
     constexpr int BLOCK = BlockCfg<LOG2N>::BLOCK;
     constexpr int SLOTS = BLOCK / BlockCfg<LOG2N>::TX;
-    constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N>() : 0;
+    constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0;
     auto kern = fft_lds_kernel<T, SC::P, typename SC::RD, kPadShift, BLOCK, VAR>;
     static thread_local int attr_dev = -1;
     int dev = 0;
