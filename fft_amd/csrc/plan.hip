@@ -8,6 +8,7 @@
 #include <new>
 
 #include "common.h"
+#include "tile_kernel.h"
 
 namespace mfft {
 
@@ -173,29 +174,51 @@ __global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_
     }
 }
 
-// ---------------------------------------------------------------------------
-// plan
-// ---------------------------------------------------------------------------
-struct Plan {
-    int64_t n = 0, n_in = 0, batch = 0;
-    int dtype = 0;
-    uint32_t flags = 0;
-    int device = 0;
-    int log2n = 0;
-    LdsGeometry geo{};
-    void* d_tw = nullptr;    // LDS-kernel twiddles
-    void* d_win = nullptr;   // real window, n_in samples (MFFT_HANN)
-    void* d_pre = nullptr;   // complex premultiplier, n_in samples (MFFT_DEMOD)
-    // staging for mfft_exec_host
-    void* d_in = nullptr;
-    void* d_out = nullptr;
-    double* d_stats = nullptr;
-    int64_t workspace = 0;
-    int launches = 1;
-    std::mutex mu;
-};
+// out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and
+// epilogue of the general path applied to sample 0.
+template <typename T>
+__global__ void n1_kernel(const void* in, void* out, int64_t batch, int64_t in_stride, int real_in,
+                          const T* win, const cx<T>* pre, T scale, int conj, int power, double* stats)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    cx<T> x{0, 0};
+    if (real_in) x.x = static_cast<const T*>(in)[b * in_stride];
+    else x = static_cast<const cx<T>*>(in)[b * in_stride];
+    if (conj) x.y = -x.y;
+    if (win) { x.x *= win[0]; x.y *= win[0]; }
+    if (pre) x = cmul(x, pre[0]);
+    x.x *= scale;
+    x.y *= scale;
+    if (conj) x.y = -x.y;
+    if (power) {
+        const T s = x.x * x.x + x.y * x.y;
+        static_cast<T*>(out)[b] = s;
+        if (stats) { stats[3 * b] = (double)s; stats[3 * b + 1] = (double)s; stats[3 * b + 2] = 0.0; }
+    } else {
+        static_cast<cx<T>*>(out)[b] = x;
+    }
+}
 
+// ---------------------------------------------------------------------------
+// power-of-two engine: one LDS-resident kernel, or 2-4 global Stockham passes
+// ---------------------------------------------------------------------------
 static size_t real_size(int dtype) { return dtype == MFFT_C64 ? sizeof(float) : sizeof(double); }
+
+// What surrounds one transform: where the data is and which prologue / epilogue applies.
+template <typename T> struct Io {
+    const void* in = nullptr;
+    void* out = nullptr;
+    int64_t in_stride = 0, out_stride = 0;
+    const T* win = nullptr;
+    const cx<T>* pre = nullptr;
+    const cx<T>* post = nullptr;
+    double* stats = nullptr;
+    int64_t n_in = 0, n_out = 0;
+    int real_in = 0, conj_in = 0, conj_out = 0;
+    T scale = 1;
+    bool power = false;
+};
 
 template <typename T>
 static int upload_complex(const std::vector<long double>& re, const std::vector<long double>& im, void** d)
@@ -207,6 +230,198 @@ static int upload_complex(const std::vector<long double>& re, const std::vector<
     if (!h.empty()) MFFT_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     return MFFT_OK;
 }
+static int upload_complex_dt(int dtype, const std::vector<long double>& re, const std::vector<long double>& im,
+                             void** d)
+{
+    return dtype == MFFT_C64 ? upload_complex<float>(re, im, d) : upload_complex<double>(re, im, d);
+}
+
+template <typename T> static int upload_real(const std::vector<long double>& v, void** d)
+{
+    std::vector<T> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = (T)v[i];
+    MFFT_HIP(hipMalloc(d, (h.empty() ? 1 : h.size()) * sizeof(T)));
+    if (!h.empty()) MFFT_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MFFT_OK;
+}
+
+struct GlobalPass {
+    int log2g = 0;
+    int64_t ns = 1;          // product of earlier radices
+    int lb = 0;              // low-table bits
+    void* d_tw = nullptr;    // inner tables of the G-point DFT
+    void* d_lo = nullptr;    // exp(-2 pi i k / M), k < 2^lb           (ns > 1 only)
+    void* d_hi = nullptr;    // exp(-2 pi i (k << lb) / M), k < M >> lb
+};
+
+struct Pow2Engine {
+    int64_t n = 0, batch = 0;
+    int dtype = 0, log2n = 0;
+    bool single = true;
+    LdsGeometry geo{};
+    void* d_tw = nullptr;               // single-kernel twiddles
+    std::vector<GlobalPass> passes;     // tiled decomposition
+    void* work[2] = {nullptr, nullptr};
+    int64_t bytes = 0;                  // device memory held
+
+    int build(int64_t n_, int64_t batch_, int dtype_);
+    void release();
+    int launches() const { return single ? 1 : (int)passes.size(); }
+    template <typename T> int exec(const Io<T>& io, hipStream_t s);
+};
+
+int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
+{
+    n = n_; batch = batch_; dtype = dtype_;
+    log2n = ilog2(n);
+    if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
+    const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
+    std::vector<long double> re, im;
+    if (log2n <= maxlog) {
+        single = true;
+        if (!lds_geometry(dtype, log2n, &geo)) { set_error("no single-kernel geometry"); return MFFT_E_UNSUPPORTED; }
+        build_lds_twiddles(geo, &re, &im);
+        bytes += (int64_t)re.size() * 2 * (int64_t)real_size(dtype);
+        return upload_complex_dt(dtype, re, im, &d_tw);
+    }
+    single = false;
+    const int log2c = dtype == MFFT_C64 ? tile_log2c_c64() : tile_log2c_c128();
+    const int npass = (log2n + kTileMaxLog2G - 1) / kTileMaxLog2G;
+    if (npass > 4) { set_error("length above 2^40"); return MFFT_E_UNSUPPORTED; }
+    // split log2n as evenly as possible, larger radices first
+    int64_t ns = 1;
+    for (int s = 0; s < npass; ++s) {
+        GlobalPass gp;
+        gp.log2g = log2n / npass + (s < log2n % npass ? 1 : 0);
+        if (gp.log2g < kTileMinLog2G || gp.log2g < log2c) { set_error("tile radix too small"); return MFFT_E_UNSUPPORTED; }
+        gp.ns = ns;
+        LdsGeometry g{};
+        if (!lds_geometry(dtype, gp.log2g, &g)) { set_error("no geometry for tile radix"); return MFFT_E_UNSUPPORTED; }
+        build_lds_twiddles(g, &re, &im);
+        int rc = upload_complex_dt(dtype, re, im, &gp.d_tw);
+        if (rc) { passes.push_back(gp); return rc; }
+        bytes += (int64_t)re.size() * 2 * (int64_t)real_size(dtype);
+        if (s > 0) {
+            const int64_t m = ns << gp.log2g;
+            const int log2m = ilog2(m);
+            gp.lb = log2m < 8 ? log2m : 8;
+            const int64_t lo_n = int64_t(1) << gp.lb, hi_n = m >> gp.lb;
+            re.resize((size_t)lo_n); im.resize((size_t)lo_n);
+            for (int64_t k = 0; k < lo_n; ++k) unit_root(k, m, &re[(size_t)k], &im[(size_t)k]);
+            rc = upload_complex_dt(dtype, re, im, &gp.d_lo);
+            if (rc) { passes.push_back(gp); return rc; }
+            re.resize((size_t)hi_n); im.resize((size_t)hi_n);
+            for (int64_t k = 0; k < hi_n; ++k) unit_root(k << gp.lb, m, &re[(size_t)k], &im[(size_t)k]);
+            rc = upload_complex_dt(dtype, re, im, &gp.d_hi);
+            if (rc) { passes.push_back(gp); return rc; }
+            bytes += (lo_n + hi_n) * 2 * (int64_t)real_size(dtype);
+        }
+        passes.push_back(gp);
+        ns <<= gp.log2g;
+    }
+    const size_t wbytes = (size_t)n * (size_t)batch * 2 * real_size(dtype);
+    const int nwork = npass > 2 ? 2 : 1;
+    for (int i = 0; i < nwork; ++i) {
+        MFFT_HIP(hipMalloc(&work[i], wbytes));
+        bytes += (int64_t)wbytes;
+    }
+    return MFFT_OK;
+}
+
+void Pow2Engine::release()
+{
+    if (d_tw) (void)hipFree(d_tw);
+    for (auto& gp : passes)
+        for (void* q : {gp.d_tw, gp.d_lo, gp.d_hi})
+            if (q) (void)hipFree(q);
+    for (void* q : work)
+        if (q) (void)hipFree(q);
+    d_tw = nullptr; work[0] = work[1] = nullptr; passes.clear();
+}
+
+template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
+{
+    if (single) {
+        KArgs<T> a{};
+        a.in = io.in; a.out = io.out;
+        a.tw = static_cast<const cx<T>*>(d_tw);
+        a.win = io.win; a.pre = io.pre; a.post = io.post; a.stats = io.stats;
+        a.batch = batch;
+        a.in_stride = io.in_stride; a.out_stride = io.out_stride;
+        a.n_in = (int)io.n_in; a.n_out = (int)io.n_out;
+        a.real_in = io.real_in; a.conj_in = io.conj_in; a.conj_out = io.conj_out;
+        a.scale = io.scale;
+        const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n;
+        const bool bare = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && !io.stats && full;
+        int variant;
+        if (io.power && io.win && bare) variant = V_HANN_POWER;
+        else if (!io.power && !io.win && bare) variant = V_PLAIN;
+        else variant = io.power ? V_GEN_POWER : V_GEN_CPLX;
+        if constexpr (sizeof(T) == 4) return launch_lds_c64(log2n, variant, a, 0, s);
+        else return launch_lds_c128(log2n, variant, a, 0, s);
+    }
+    const int np = (int)passes.size();
+    const void* src = io.in;
+    int64_t src_stride = io.in_stride;
+    for (int p = 0; p < np; ++p) {
+        const GlobalPass& gp = passes[(size_t)p];
+        const bool first = p == 0, last = p == np - 1;
+        TArgs<T> a{};
+        a.in = src;
+        a.in_stride = src_stride;
+        a.out = last ? io.out : work[p & 1];
+        a.out_stride = last ? io.out_stride : n;
+        a.tw = static_cast<const cx<T>*>(gp.d_tw);
+        a.tw_lo = static_cast<const cx<T>*>(gp.d_lo);
+        a.tw_hi = static_cast<const cx<T>*>(gp.d_hi);
+        a.L = n >> gp.log2g;
+        a.NS = gp.ns;
+        a.batch = batch;
+        a.lb = gp.lb;
+        a.scale = 1;
+        if (first) {
+            a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
+            a.real_in = io.real_in; a.conj_in = io.conj_in;
+        }
+        if (last) {
+            a.post = io.post; a.stats = io.stats; a.n_out = io.n_out;
+            a.conj_out = io.conj_out; a.scale = io.scale;
+        }
+        const int mode = first ? TM_FIRST : (last ? (io.power ? TM_LAST_POWER : TM_LAST_CPLX) : TM_MID);
+        int rc;
+        if constexpr (sizeof(T) == 4) rc = launch_tile_c64(gp.log2g, mode, a, s);
+        else rc = launch_tile_c128(gp.log2g, mode, a, s);
+        if (rc) return rc;
+        src = a.out;
+        src_stride = n;
+    }
+    return MFFT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct Plan {
+    int64_t n = 0, n_in = 0, batch = 0;
+    int dtype = 0;
+    uint32_t flags = 0;
+    int device = 0;
+    enum Kind { ONE_POINT, POW2, CHIRPZ } kind = POW2;
+    Pow2Engine eng;          // length n (POW2) or the padded length m (CHIRPZ)
+    int64_t m = 0;           // chirp-z convolution length
+    void* d_win = nullptr;   // real window, n_in samples (MFFT_HANN)
+    void* d_pre = nullptr;   // complex premultiplier, n_in samples (DEMOD and/or chirp)
+    void* d_chirp = nullptr; // exp(-i pi j^2 / n), j < n            (CHIRPZ)
+    void* d_filt = nullptr;  // conj(FFT_m(conj chirp, wrapped)), m   (CHIRPZ)
+    void* d_conv = nullptr;  // batch * m complex workspace            (CHIRPZ)
+    // staging for mfft_exec_host
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    double* d_stats = nullptr;
+    int64_t workspace = 0;
+    int launches = 1;
+    std::mutex mu;
+};
 
 // symmetric Hann window of m samples, np.hanning's formula, evaluated in long double
 static void hann_window(int64_t m, std::vector<long double>* w)
@@ -220,44 +435,80 @@ static void hann_window(int64_t m, std::vector<long double>* w)
     (*w)[(size_t)m - 1] = 0.0L;
 }
 
-template <typename T> static int upload_real(const std::vector<long double>& v, void** d)
-{
-    std::vector<T> h(v.size());
-    for (size_t i = 0; i < v.size(); ++i) h[i] = (T)v[i];
-    MFFT_HIP(hipMalloc(d, (h.empty() ? 1 : h.size()) * sizeof(T)));
-    if (!h.empty()) MFFT_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    return MFFT_OK;
-}
-
 static void plan_free(Plan* p)
 {
     if (!p) return;
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     (void)hipSetDevice(p->device);
-    for (void* q : {p->d_tw, p->d_win, p->d_pre, p->d_in, p->d_out, (void*)p->d_stats})
+    p->eng.release();
+    for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats})
         if (q) (void)hipFree(q);
     if (have_prev) (void)hipSetDevice(prev);
     delete p;
 }
 
+template <typename T> static int launch_premul(Plan* p, double mu, double t0, double dt, int demod, hipStream_t s)
+{
+    const int n = (int)p->n_in;
+    hipLaunchKernelGGL(premul_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<cx<T>*>(p->d_pre),
+                       static_cast<const T*>(p->d_win), static_cast<const cx<T>*>(p->d_chirp), n, mu, t0, dt,
+                       demod);
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+template <typename T> static int build_chirpz(Plan* p)
+{
+    // chirp c[j] = exp(-i pi j^2 / n) with j^2 reduced mod 2n exactly
+    const int64_t n = p->n, m = p->m;
+    std::vector<long double> cr((size_t)n), ci((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t jj = (int64_t)(((unsigned __int128)j * (unsigned __int128)j) % (unsigned __int128)(2 * n));
+        unit_root(jj, 2 * n, &cr[(size_t)j], &ci[(size_t)j]);
+    }
+    int rc = upload_complex<T>(cr, ci, &p->d_chirp);
+    if (rc) return rc;
+    // filter b[d] = conj(c[|d|]) for -n_in < d < n, wrapped into m points
+    std::vector<cx<T>> hb((size_t)m, cx<T>{0, 0});
+    for (int64_t d = 0; d < n; ++d) hb[(size_t)d] = cx<T>{(T)cr[(size_t)d], (T)(-ci[(size_t)d])};
+    for (int64_t d = 1; d < p->n_in; ++d) hb[(size_t)(m - d)] = cx<T>{(T)cr[(size_t)d], (T)(-ci[(size_t)d])};
+    void* d_b = nullptr;
+    MFFT_HIP(hipMalloc(&d_b, (size_t)m * sizeof(cx<T>)));
+    hipError_t e = hipMemcpy(d_b, hb.data(), (size_t)m * sizeof(cx<T>), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
+    MFFT_HIP(hipMalloc(&p->d_filt, (size_t)m * sizeof(cx<T>)));
+    // one-signal engine for the filter transform; conj_out stores conj(FFT(b)), the form the
+    // first stage multiplies by
+    Pow2Engine one;
+    rc = one.build(m, 1, p->dtype);
+    if (rc == MFFT_OK) {
+        Io<T> io;
+        io.in = d_b; io.out = p->d_filt; io.in_stride = m; io.out_stride = m;
+        io.n_in = m; io.n_out = m; io.conj_out = 1;
+        rc = one.exec<T>(io, nullptr);
+        if (rc == MFFT_OK) {
+            e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = hip_fail(e, "hipDeviceSynchronize", __FILE__, __LINE__);
+        }
+    }
+    one.release();
+    (void)hipFree(d_b);
+    if (rc) return rc;
+    MFFT_HIP(hipMalloc(&p->d_conv, (size_t)m * (size_t)p->batch * sizeof(cx<T>)));
+    MFFT_HIP(hipMalloc(&p->d_pre, (size_t)p->n_in * sizeof(cx<T>)));
+    p->workspace += (int64_t)((size_t)n + 2 * (size_t)m + (size_t)m * (size_t)p->batch + (size_t)p->n_in) * (int64_t)sizeof(cx<T>);
+    if (!(p->flags & MFFT_DEMOD)) {
+        rc = launch_premul<T>(p, 0.0, 0.0, 0.0, 0, nullptr);   // static premultiplier: window * chirp
+        if (rc) return rc;
+        MFFT_HIP(hipDeviceSynchronize());
+    }
+    return MFFT_OK;
+}
+
 static int plan_build(Plan* p)
 {
-    if (!is_pow2(p->n)) {
-        set_error("only power-of-two lengths are implemented in this build step");
-        return MFFT_E_UNSUPPORTED;
-    }
-    p->log2n = ilog2(p->n);
-    if (p->n == 1 || !lds_geometry(p->dtype, p->log2n, &p->geo)) {
-        set_error("length outside the single-kernel range");
-        return MFFT_E_UNSUPPORTED;
-    }
-    std::vector<long double> re, im;
-    build_lds_twiddles(p->geo, &re, &im);
-    int rc = p->dtype == MFFT_C64 ? upload_complex<float>(re, im, &p->d_tw)
-                                  : upload_complex<double>(re, im, &p->d_tw);
-    if (rc) return rc;
-    p->workspace += (int64_t)re.size() * 2 * (int64_t)real_size(p->dtype);
+    int rc;
     if (p->flags & MFFT_HANN) {
         std::vector<long double> w;
         hann_window(p->n_in, &w);
@@ -265,11 +516,34 @@ static int plan_build(Plan* p)
         if (rc) return rc;
         p->workspace += p->n_in * (int64_t)real_size(p->dtype);
     }
-    if (p->flags & MFFT_DEMOD) {
-        MFFT_HIP(hipMalloc(&p->d_pre, (size_t)p->n_in * 2 * real_size(p->dtype)));
-        p->workspace += p->n_in * 2 * (int64_t)real_size(p->dtype);
-        p->launches += 1;
+    if (p->n == 1) {
+        p->kind = Plan::ONE_POINT;
+        if (p->flags & MFFT_DEMOD) MFFT_HIP(hipMalloc(&p->d_pre, 2 * real_size(p->dtype)));
+        p->launches = 1 + ((p->flags & MFFT_DEMOD) ? 1 : 0);
+        return MFFT_OK;
     }
+    if (is_pow2(p->n)) {
+        p->kind = Plan::POW2;
+        rc = p->eng.build(p->n, p->batch, p->dtype);
+        if (rc) return rc;
+        if (p->flags & MFFT_DEMOD) {
+            MFFT_HIP(hipMalloc(&p->d_pre, (size_t)p->n_in * 2 * real_size(p->dtype)));
+            p->workspace += p->n_in * 2 * (int64_t)real_size(p->dtype);
+        }
+        p->workspace += p->eng.bytes;
+        p->launches = p->eng.launches() + ((p->flags & MFFT_DEMOD) ? 1 : 0);
+        return MFFT_OK;
+    }
+    // arbitrary length: chirp-z on the next power of two that holds the linear convolution
+    p->kind = Plan::CHIRPZ;
+    p->m = 1;
+    while (p->m < p->n + p->n_in - 1) p->m <<= 1;
+    rc = p->eng.build(p->m, p->batch, p->dtype);
+    if (rc) return rc;
+    rc = p->dtype == MFFT_C64 ? build_chirpz<float>(p) : build_chirpz<double>(p);
+    if (rc) return rc;
+    p->workspace += p->eng.bytes;
+    p->launches = 2 * p->eng.launches() + ((p->flags & MFFT_DEMOD) ? 1 : 0);
     return MFFT_OK;
 }
 
@@ -277,54 +551,67 @@ template <typename T>
 static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
                       double* d_stats, hipStream_t s)
 {
-    KArgs<T> a{};
-    a.in = d_in;
-    a.out = d_out;
-    a.tw = static_cast<const cx<T>*>(p->d_tw);
-    a.win = static_cast<const T*>(p->d_win);
-    a.pre = nullptr;
-    a.post = nullptr;
-    a.stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
-    a.batch = p->batch;
-    a.in_stride = p->n_in;
-    a.out_stride = p->n;
-    a.n_in = (int)p->n_in;
-    a.n_out = (int)p->n;
-    a.real_in = (p->flags & MFFT_REAL_IN) ? 1 : 0;
-    a.conj_in = (p->flags & MFFT_INVERSE) ? 1 : 0;
-    a.conj_out = (p->flags & MFFT_INVERSE) ? 1 : 0;
-    a.scale = (T)scale;
-
-    if (p->flags & MFFT_DEMOD) {
-        const int n = (int)p->n_in;
-        hipLaunchKernelGGL(premul_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s,
-                           static_cast<cx<T>*>(p->d_pre), static_cast<const T*>(p->d_win),
-                           (const cx<T>*)nullptr, n, mu, t0, dt, 1);
-        MFFT_HIP(hipGetLastError());
-        a.pre = static_cast<const cx<T>*>(p->d_pre);
-        a.win = nullptr;   // folded into pre
-    }
-    if (a.stats) MFFT_HIP(hipMemsetAsync(a.stats, 0, sizeof(double) * 3 * (size_t)p->batch, s));
-
+    const bool demod = (p->flags & MFFT_DEMOD) != 0;
     const bool power = (p->flags & MFFT_POWER) != 0;
-    const uint32_t prologue = p->flags & (MFFT_DEMOD | MFFT_REAL_IN | MFFT_INVERSE);
-    const bool full = p->n_in == p->n;
-    int variant;
-    if (power && (p->flags & MFFT_HANN) && !prologue && full && !a.stats) variant = V_HANN_POWER;
-    else if (!power && !(p->flags & MFFT_HANN) && !prologue && full) variant = V_PLAIN;
-    else variant = power ? V_GEN_POWER : V_GEN_CPLX;
+    const bool inverse = (p->flags & MFFT_INVERSE) != 0;
+    double* stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
+    if (stats) MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)p->batch, s));
+    if (demod) {
+        const int rc = launch_premul<T>(p, mu, t0, dt, 1, s);
+        if (rc) return rc;
+    }
+    const T* win = static_cast<const T*>(p->d_win);
+    const cx<T>* pre = static_cast<const cx<T>*>(p->d_pre);
 
-    if constexpr (sizeof(T) == 4) return launch_lds_c64(p->log2n, variant, a, 0, s);
-    else return launch_lds_c128(p->log2n, variant, a, 0, s);
+    if (p->kind == Plan::ONE_POINT) {
+        const int64_t blocks = (p->batch + 255) / 256;
+        hipLaunchKernelGGL(n1_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, d_in, d_out, p->batch, p->n_in,
+                           (p->flags & MFFT_REAL_IN) ? 1 : 0, demod ? (const T*)nullptr : win,
+                           demod ? pre : (const cx<T>*)nullptr, (T)scale, inverse ? 1 : 0, power ? 1 : 0, stats);
+        MFFT_HIP(hipGetLastError());
+        return MFFT_OK;
+    }
+    if (p->kind == Plan::POW2) {
+        Io<T> io;
+        io.in = d_in; io.out = d_out;
+        io.in_stride = p->n_in; io.out_stride = p->n;
+        io.win = demod ? nullptr : win;          // with DEMOD the window is folded into pre
+        io.pre = demod ? pre : nullptr;
+        io.stats = stats;
+        io.n_in = p->n_in; io.n_out = p->n;
+        io.real_in = (p->flags & MFFT_REAL_IN) ? 1 : 0;
+        io.conj_in = inverse; io.conj_out = inverse;
+        io.scale = (T)scale;
+        io.power = power;
+        return p->eng.exec<T>(io, s);
+    }
+    // chirp-z: X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j]
+    if (inverse) { set_error("MFFT_INVERSE is implemented for power-of-two lengths only"); return MFFT_E_UNSUPPORTED; }
+    Io<T> a;                                        // stage 1: conj(FFT_m(x * pre) ) * conj(FFT_m(b))
+    a.in = d_in; a.out = p->d_conv;
+    a.in_stride = p->n_in; a.out_stride = p->m;
+    a.pre = pre;                                    // window * demod * chirp
+    a.post = static_cast<const cx<T>*>(p->d_filt);
+    a.n_in = p->n_in; a.n_out = p->m;
+    a.real_in = (p->flags & MFFT_REAL_IN) ? 1 : 0;
+    a.conj_out = 1;
+    int rc = p->eng.exec<T>(a, s);
+    if (rc) return rc;
+    Io<T> b;                                        // stage 2: conj(FFT_m(.)) / m * c[k], first n bins
+    b.in = p->d_conv; b.out = d_out;
+    b.in_stride = p->m; b.out_stride = p->n;
+    b.post = static_cast<const cx<T>*>(p->d_chirp);
+    b.stats = stats;
+    b.n_in = p->m; b.n_out = p->n;
+    b.conj_out = 1;
+    b.scale = (T)(scale / (double)p->m);
+    b.power = power;
+    return p->eng.exec<T>(b, s);
 }
 
 static int plan_exec(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
                      double* d_stats, hipStream_t s)
 {
-    if ((p->flags & MFFT_STATS) && !(p->flags & MFFT_POWER)) {
-        set_error("MFFT_STATS needs MFFT_POWER");
-        return MFFT_E_INVALID;
-    }
     return p->dtype == MFFT_C64 ? exec_typed<float>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s)
                                 : exec_typed<double>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
 }

@@ -1,0 +1,10 @@
+// Instantiates the global-pass (tile) kernels for complex128.
+#include "tile_kernel.h"
+
+namespace mfft {
+int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s)
+{
+    return launch_tile_any<double>(log2g, mode, a, s);
+}
+int tile_log2c_c128() { return TileCols<double>::LOG2C; }
+}  // namespace mfft

@@ -1,0 +1,10 @@
+// Instantiates the global-pass (tile) kernels for complex64.
+#include "tile_kernel.h"
+
+namespace mfft {
+int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s)
+{
+    return launch_tile_any<float>(log2g, mode, a, s);
+}
+int tile_log2c_c64() { return TileCols<float>::LOG2C; }
+}  // namespace mfft

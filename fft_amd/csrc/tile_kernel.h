@@ -1,0 +1,291 @@
+// One global Stockham pass for transforms too long for a single LDS residency.
+//
+// A transform of N = G_0 * G_1 * ... points runs as a few out-of-place passes over
+// HBM, each the autosort step of radix G_s ("super-butterflies" of G_s points):
+//
+//   super-butterfly j in [0, L), L = N / G:
+//     reads   x[j + i*L]                                    i < G     (row stride L)
+//     twiddle x_i *= exp(-2*pi*i * (j mod NS)*i / (NS*G))              (NS = G_0*...*G_{s-1})
+//     G-point DFT
+//     writes  y[(j / NS)*NS*G + (j mod NS) + q*NS]          q < G     (row stride NS)
+//
+// so the output of the last pass is in natural order and no transpose or
+// bit-reversal pass exists.  A workgroup owns C consecutive super-butterflies:
+// its input is a G x C tile whose rows are C contiguous elements (C*8 B = one
+// 128-B line for complex64 at C = 16), its output a G x C tile with the same
+// property (for the first pass, where NS = 1, the tile is one contiguous run of
+// C*G elements).  The G-point DFTs of the C columns run in LDS with the same
+// register butterflies and Stockham exchanges as the batched kernel; the LDS image
+// is [position][column] with an odd pitch so that both "lanes along a row" and
+// "lanes down a column" are conflict-free.
+//
+// The twiddle exp(-2*pi*i*k/M), k = (j mod NS)*i < M = NS*G, comes from a two-level
+// table: low 2^LB entries staged in LDS, high M/2^LB entries read through L2.
+#pragma once
+#include "lds_kernel.h"
+
+namespace mfft {
+
+template <typename T> struct TArgs {
+    const void* in;
+    void* out;
+    const cx<T>* tw;      // inner per-pass tables for the G-point DFT
+    const cx<T>* tw_lo;   // exp(-2*pi*i*k/M),        k < 2^lb
+    const cx<T>* tw_hi;   // exp(-2*pi*i*(k<<lb)/M),  k < M >> lb
+    const T* win;         // FIRST: real window over the n_in input samples, or nullptr
+    const cx<T>* pre;     // FIRST: complex premultiplier, or nullptr
+    const cx<T>* post;    // LAST: complex postmultiplier over the n_out bins, or nullptr
+    double* stats;        // LAST + power: 3 doubles per signal, or nullptr
+    int64_t L;            // N / G: input row stride = number of super-butterflies
+    int64_t NS;           // product of the radices of the earlier passes
+    int64_t batch;
+    int64_t in_stride;    // elements between signals in `in`
+    int64_t out_stride;   // elements between signals in `out`
+    int64_t n_in;         // FIRST: samples present per signal
+    int64_t n_out;        // LAST: bins stored per signal
+    int lb;
+    int real_in, conj_in, conj_out;
+    T scale;
+};
+
+enum TileMode { TM_MID = 0, TM_FIRST = 1, TM_LAST_CPLX = 2, TM_LAST_POWER = 3 };
+
+template <int LOG2G> struct TileCfg {
+    using SC = SizeCfg<LOG2G>;
+    static constexpr int G = 1 << LOG2G;
+    static constexpr int P = SC::P;
+    static constexpr int TX = G / P;
+};
+
+// position -> LDS element index for column c: padded position times the odd pitch
+template <int PADSHIFT, int PITCH> __device__ __forceinline__ int tile_addr(int pos, int c)
+{
+    return lds_pad<PADSHIFT>(pos) * PITCH + c;
+}
+
+template <typename T, class RD, int S, int P, int TX, int PADSHIFT, int PITCH>
+__device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>* lds)
+{
+    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + TX * u;
+        const int base = (j / NS) * (NS * R) + (j % NS);
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[tile_addr<PADSHIFT, PITCH>(base + q * NS, c)] = v[u + U * q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P; ++e) v[e] = lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)];
+}
+
+template <typename T, int LOG2G, int LOG2C, int MODE>
+__global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel(const TArgs<T> a)
+{
+    using C_ = cx<T>;
+    using TC = TileCfg<LOG2G>;
+    using RD = typename TC::SC::RD;
+    constexpr int G = TC::G, P = TC::P, TX = TC::TX;
+    constexpr int C = 1 << LOG2C;
+    constexpr int BLOCK = TX * C;
+    constexpr int PITCH = C + 1;
+    constexpr int PADSHIFT = kPadShift;
+    constexpr int NPASS = RD::npass;
+    constexpr int LDS_ELEMS = (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
+    constexpr int LO_MAX = 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C_* lds = reinterpret_cast<C_*>(smem_raw);
+    C_* lo = lds + LDS_ELEMS;                 // low twiddle table (MODE != FIRST)
+
+    const int c = threadIdx.x % C;            // column of the tile = lane-fastest
+    const int t = threadIdx.x / C;            // thread within the column's DFT
+    if constexpr (MODE != TM_FIRST) {
+        for (int i = threadIdx.x; i < (1 << a.lb); i += BLOCK) lo[i] = a.tw_lo[i];
+        __syncthreads();
+    }
+    (void)LO_MAX;
+
+    const int64_t tiles_per_signal = a.L / C;
+    const int64_t total = tiles_per_signal * a.batch;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t b = w / tiles_per_signal;
+        const int64_t j0 = (w - b * tiles_per_signal) * C;
+        const int64_t j = j0 + c;
+        C_ v[P];
+
+        // ---- load the G x C tile (row i = t + TX*e, column c) --------------------
+        if constexpr (MODE == TM_FIRST) {
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int64_t idx = j + (int64_t)(t + TX * e) * a.L;   // sample index in the signal
+                C_ x{0, 0};
+                if (idx < a.n_in) {
+                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[b * a.in_stride + idx];
+                    else x = reinterpret_cast<const C_*>(a.in)[b * a.in_stride + idx];
+                    if (a.conj_in) x.y = -x.y;
+                    if (a.win) { const T wv = a.win[idx]; x.x *= wv; x.y *= wv; }
+                    if (a.pre) x = cmul(x, a.pre[idx]);
+                }
+                v[e] = x;
+            }
+        } else {
+            const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
+            const int64_t m = j % a.NS;
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = src[(int64_t)(t + TX * e) * a.L];
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int64_t k = m * (int64_t)(t + TX * e);
+                const C_ wl = lo[k & ((1 << a.lb) - 1)];
+                const C_ wh = a.tw_hi[k >> a.lb];
+                v[e] = cmul(v[e], cmul(wl, wh));
+            }
+        }
+
+        // ---- G-point DFT of every column, in LDS -----------------------------------
+        pass_compute<T, RD, 0, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+        if constexpr (NPASS > 1) {
+            tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            pass_compute<T, RD, 1, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+        }
+        if constexpr (NPASS > 2) {
+            tile_exchange<T, RD, 1, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            pass_compute<T, RD, 2, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+        }
+        if constexpr (NPASS > 3) {
+            tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            pass_compute<T, RD, 3, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+        }
+        // v[e] = output q = t + TX*e of column c
+
+        // ---- store -------------------------------------------------------------------
+        if constexpr (MODE == TM_FIRST) {
+            // NS = 1: y[(j0 + c)*G + q] -- the tile is one contiguous run of C*G elements,
+            // q fastest.  Turn the registers through LDS so that lanes run along q.
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < P; ++e) lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)] = v[e];
+            __syncthreads();
+            C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j0 * G;
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int r = threadIdx.x + BLOCK * e;      // element of the run: r = cc*G + q
+                const int cc = r / G, q = r % G;
+                dst[r] = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
+            }
+        } else if constexpr (MODE == TM_MID) {
+            const int64_t m = j % a.NS;
+            C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + (j / a.NS) * a.NS * G + m;
+#pragma unroll
+            for (int e = 0; e < P; ++e) dst[(int64_t)(t + TX * e) * a.NS] = v[e];
+        } else {
+            // last pass: NS*G = N, so j < NS and bin k = j + q*NS
+            double mx = 0.0, sm = 0.0, sk = 0.0;
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int64_t k = j + (int64_t)(t + TX * e) * a.NS;
+                C_ o{v[e].x * a.scale, v[e].y * a.scale};
+                if (a.conj_out) o.y = -o.y;
+                if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
+                if constexpr (MODE == TM_LAST_POWER) {
+                    const T s = o.x * o.x + o.y * o.y;
+                    if (k < a.n_out) {
+                        reinterpret_cast<T*>(a.out)[b * a.out_stride + k] = s;
+                        const double f = (k < (a.n_out + 1) / 2) ? (double)k : (double)(k - a.n_out);
+                        mx = (double)s > mx ? (double)s : mx;
+                        sm += (double)s;
+                        sk += f * (double)s;
+                    }
+                } else {
+                    if (k < a.n_out) reinterpret_cast<C_*>(a.out)[b * a.out_stride + k] = o;
+                }
+            }
+            if constexpr (MODE == TM_LAST_POWER) {
+                if (a.stats != nullptr) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double omx = __shfl_xor(mx, o, 64);
+                        mx = omx > mx ? omx : mx;
+                        sm += __shfl_xor(sm, o, 64);
+                        sk += __shfl_xor(sk, o, 64);
+                    }
+                    if ((threadIdx.x & 63) == 0) {
+                        double* st = a.stats + 3 * b;
+                        atomicMax(reinterpret_cast<unsigned long long*>(st),
+                                  (unsigned long long)__double_as_longlong(mx));
+                        atomicAdd(st + 1, sm);
+                        atomicAdd(st + 2, sk);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int LOG2G, int LOG2C> constexpr size_t tile_lds_bytes()
+{
+    constexpr int G = 1 << LOG2G, C = 1 << LOG2C;
+    return ((size_t)(lds_pad<kPadShift>(G - 1) + 1) * (C + 1) + 256) * sizeof(cx<T>);
+}
+
+template <typename T, int LOG2G, int LOG2C, int MODE>
+int launch_tile_one(const TArgs<T>& a, hipStream_t s)
+{
+    constexpr int BLOCK = TileCfg<LOG2G>::TX << LOG2C;
+    constexpr size_t lds = tile_lds_bytes<T, LOG2G, LOG2C>();
+    static_assert(BLOCK <= 1024, "tile workgroup too large");
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    auto kern = fft_tile_kernel<T, LOG2G, LOG2C, MODE>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    MFFT_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_dev = dev;
+    }
+    const int64_t total = (a.L >> LOG2C) * a.batch;
+    if (total <= 0) return MFFT_OK;
+    const int grid = pick_grid(reinterpret_cast<const void*>(kern), BLOCK, lds, total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+template <typename T, int LOG2G, int LOG2C>
+int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
+{
+    switch (mode) {
+    case TM_MID: return launch_tile_one<T, LOG2G, LOG2C, TM_MID>(a, s);
+    case TM_FIRST: return launch_tile_one<T, LOG2G, LOG2C, TM_FIRST>(a, s);
+    case TM_LAST_CPLX: return launch_tile_one<T, LOG2G, LOG2C, TM_LAST_CPLX>(a, s);
+    case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LOG2C, TM_LAST_POWER>(a, s);
+    }
+    set_error("unknown tile mode");
+    return MFFT_E_INVALID;
+}
+
+// Column count per tile: 16 complex64 (128-B rows); complex128 uses 8 (128-B rows),
+// which is also what keeps the 1024-point tile inside 160 KiB.
+template <typename T> struct TileCols { static constexpr int LOG2C = sizeof(T) == 4 ? 4 : 3; };
+
+template <typename T>
+int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
+{
+    constexpr int LC = TileCols<T>::LOG2C;
+    switch (log2g) {
+    case 4: return launch_tile_mode<T, 4, LC>(mode, a, s);
+    case 5: return launch_tile_mode<T, 5, LC>(mode, a, s);
+    case 6: return launch_tile_mode<T, 6, LC>(mode, a, s);
+    case 7: return launch_tile_mode<T, 7, LC>(mode, a, s);
+    case 8: return launch_tile_mode<T, 8, LC>(mode, a, s);
+    case 9: return launch_tile_mode<T, 9, LC>(mode, a, s);
+    case 10: return launch_tile_mode<T, 10, LC>(mode, a, s);
+    }
+    set_error("tile radix outside 16..1024");
+    return MFFT_E_UNSUPPORTED;
+}
+
+}  // namespace mfft

@@ -1,0 +1,102 @@
+"""GPU parity for the multi-kernel paths: global Stockham passes (lengths above
+one LDS residency) and the chirp-z wrapper (lengths that are not powers of two),
+through the C ABI, against the CPU oracle.  Tolerances as in BASELINE.json:
+relative L2 <= 1e-5 (complex64) / 1e-12 (complex128) against float64."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-5, 1: 1e-12}
+
+
+def _rand(shape, seed, dtype):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fft_amd
+    assert fft_amd.device_count() >= 1
+    return fft_amd
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("log2n", [14, 15, 16, 17, 18, 19, 20, 21, 22])
+def test_tiled_pow2(fa, dtype, log2n):
+    if dtype == 0 and log2n == 14:
+        pytest.skip("single-kernel length for complex64")
+    n = 1 << log2n
+    batch = 3 if log2n <= 16 else 1
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), log2n + 10 * dtype, cdt)
+    with fa.Plan(n, batch=batch, dtype=dtype) as p:
+        assert p.launches >= 2
+        y = p.exec_host(x)
+    assert rel_l2(y, so.dft(x, engine="numpy")) < TOL[dtype]
+
+
+def test_cfg3_2pow24_c64(fa):
+    """BASELINE config 3: one complex64 transform of 2^24 points."""
+    n = 1 << 24
+    x = _rand((1, n), 24, np.complex64)
+    with fa.Plan(n, dtype=0) as p:
+        y = p.exec_host(x)
+    ref = np.fft.fft(x.astype(np.complex128))
+    assert rel_l2(y, ref) < 1e-5
+    # size-independent properties at full size: Parseval and a shifted impulse
+    e_in = float(np.sum(np.abs(x.astype(np.complex128)) ** 2))
+    assert abs(float(np.sum(np.abs(y.astype(np.complex128)) ** 2)) / (n * e_in) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n", [1, 3, 5, 6, 7, 12, 30, 100, 127, 1000, 1501, 8001, 24016, 100003])
+def test_chirpz_arbitrary_length(fa, dtype, n):
+    batch = 2
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), n + dtype, cdt)
+    with fa.Plan(n, batch=batch, dtype=dtype) as p:
+        y = p.exec_host(x)
+    assert y.shape == (batch, n)
+    ref = so.dft(x, engine="numpy")
+    assert rel_l2(y, ref) < (3e-5 if dtype == 0 else TOL[1])   # three fp32 transforms back to back
+    if n <= 1000:
+        assert rel_l2(y[0], so.dft(x[0], engine="direct")) < (3e-5 if dtype == 0 else TOL[1])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_app_lengths_window_pad_power_stats(fa, dtype):
+    """The reference apps' own call shapes: N0 = 8001 -> 256032 (final2 defaults) and
+    N0 = 1501 -> 24016 with demodulation (combined app defaults)."""
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    for n_in, n, mu in ((8001, 256032, 0.0), (1501, 24016, -0.81)):
+        dt = 0.01
+        times = np.arange(n_in) * dt
+        x = _rand((1, n_in), n_in, cdt)
+        flags = fa.HANN | fa.POWER | fa.STATS | (fa.DEMOD if mu else 0)
+        with fa.Plan(n, n_in=n_in, dtype=dtype, flags=flags) as p:
+            S, stats = p.exec_host(x, scale=dt, mu=mu, t0=0.0, dt=dt)
+        _, ref = so.windowed_power(x, n=n, use_hann=True, dt=dt, engine="numpy", mu=mu or None, times=times)
+        assert rel_l2(S, ref) < (6e-5 if dtype == 0 else 2e-12)
+        tol = 1e-4 if dtype == 0 else 1e-11
+        assert abs(stats[0, 0] - ref.max()) < tol * ref.max()
+        assert abs(stats[0, 1] - ref.sum()) < tol * ref.sum()
+        f = np.fft.fftfreq(n) * n
+        assert abs(stats[0, 2] - (ref * f).sum()) < tol * np.abs(ref * f).sum()
+
+
+def test_real_input_chirpz_and_one_point(fa):
+    rng = np.random.default_rng(11)
+    xr = rng.standard_normal((2, 1000))
+    with fa.Plan(1000, batch=2, dtype=1, flags=fa.REAL_IN) as p:
+        y = p.exec_host(xr)
+    assert rel_l2(y, np.fft.fft(xr)) < 1e-12
+    x1 = _rand((5, 1), 1, np.complex128)
+    with fa.Plan(1, batch=5, dtype=1, flags=fa.POWER | fa.STATS) as p:
+        S, st = p.exec_host(x1, scale=2.0)
+    assert np.allclose(S[:, 0], np.abs(2.0 * x1[:, 0]) ** 2, rtol=1e-14)
+    assert np.allclose(st[:, 0], S[:, 0]) and np.allclose(st[:, 2], 0.0)
