@@ -4,10 +4,16 @@ Layers (bottom up):
   csrc/        hand-written HIP kernels + the C ABI of include/mfft.h -> lib/libmfft.so
   _lib.py      ctypes binding of that ABI
   engine.py    Plan objects over device or host buffers
+  npfft.py     numpy-compatible fft / fftfreq served by the GPU
+  spectral.py  drop-ins for the reference's fft_from_timeseries / fft_extract_E_p
+  dist.py      one-process-per-GPU sharding: batches, 2-D pencils, large 1-D (torch.distributed / RCCL)
 """
 from . import _lib
 from .engine import Plan
 from ._lib import C64, C128, HANN, POWER, DEMOD, REAL_IN, STATS, INVERSE, MfftError, device_count
+from .npfft import fft, fftfreq, clear_plan_cache
+from .spectral import fft_from_timeseries, fft_extract_E_p, power_spectrum, return_amplitude
 
 __all__ = ["Plan", "C64", "C128", "HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE",
-           "MfftError", "device_count"]
+           "MfftError", "device_count", "fft", "fftfreq", "clear_plan_cache",
+           "fft_from_timeseries", "fft_extract_E_p", "power_spectrum", "return_amplitude"]

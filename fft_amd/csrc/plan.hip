@@ -721,9 +721,10 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale, doubl
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu, double t0,
                    double dt, double* h_stats)
 {
-    if (!plan || !h_in || !h_out) { set_error("null argument"); return MFFT_E_INVALID; }
+    if (!plan || !h_in) { set_error("null argument"); return MFFT_E_INVALID; }
     Plan* p = reinterpret_cast<Plan*>(plan);
     if ((p->flags & MFFT_STATS) && !h_stats) { set_error("plan has MFFT_STATS but h_stats is null"); return MFFT_E_INVALID; }
+    if (!h_out && !(p->flags & MFFT_STATS)) { set_error("h_out may be null only when the plan returns stats"); return MFFT_E_INVALID; }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
     std::lock_guard<std::mutex> lock(p->mu);
@@ -737,7 +738,7 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     MFFT_HIP(hipMemcpy(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice));
     const int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
     if (rc != MFFT_OK) return rc;
-    MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
+    if (h_out) MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
     if (p->flags & MFFT_STATS)
         MFFT_HIP(hipMemcpy(h_stats, p->d_stats, sizeof(double) * 3 * (size_t)p->batch, hipMemcpyDeviceToHost));
     return MFFT_OK;

@@ -80,7 +80,7 @@ class Plan:
                                          float(t0), float(dt), _addr(d_stats), int(stream) or None))
 
     def exec_host(self, x: np.ndarray, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0,
-                  dt: float = 1.0):
+                  dt: float = 1.0, stats_only: bool = False):
         """Synchronous execution on a numpy array of shape (batch, n_in) (or (n_in,)
         when batch == 1).  Returns the output array, plus a (batch, 3) float64 array
         {max S, sum S, sum f_k S} when the plan has the STATS flag."""
@@ -90,12 +90,16 @@ class Plan:
         if x.size != self.batch * self.n_in:
             raise ValueError(f"input has {x.size} elements, plan expects {self.batch}x{self.n_in}")
         lead = x.shape[:-1] if x.ndim > 1 else ()
-        out = np.empty(lead + (self.n,), dtype=self.out_dtype)
         stats = np.zeros((self.batch, 3), dtype=np.float64) if self.flags & _lib.STATS else None
+        if stats_only and stats is None:
+            raise ValueError("stats_only needs a plan with the STATS flag")
+        out = None if stats_only else np.empty(lead + (self.n,), dtype=self.out_dtype)
         with self._lock:
             _lib.check(_lib.load().mfft_exec_host(
-                self._h, x.ctypes.data, out.ctypes.data, float(scale), float(mu), float(t0), float(dt),
-                stats.ctypes.data if stats is not None else None))
+                self._h, x.ctypes.data, out.ctypes.data if out is not None else None, float(scale),
+                float(mu), float(t0), float(dt), stats.ctypes.data if stats is not None else None))
+        if stats_only:
+            return stats
         return (out, stats) if stats is not None else out
 
     # -- lifetime ---------------------------------------------------------------

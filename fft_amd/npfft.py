@@ -1,0 +1,104 @@
+"""numpy-compatible entry points served by the GPU engine.
+
+``fft`` has the signature and semantics of ``numpy.fft.fft`` -- the one call the
+reference makes on its spectral path (final2.py:143,
+streamlit_app_combined.py:204, :213) -- and ``fftfreq`` those of
+``numpy.fft.fftfreq`` (final2.py:144).  Arrays go in and come out as numpy
+arrays; the transform itself always runs on the GPU (no host fallback).
+"""
+from __future__ import annotations
+
+import threading
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .engine import Plan
+
+_CACHE_MAX = 24
+_cache: "OrderedDict[tuple, Plan]" = OrderedDict()
+_cache_lock = threading.Lock()
+
+
+def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int) -> Plan:
+    """Plans own device tables and workspace, so they are kept and reused.  The
+    cache is shared by all threads (Streamlit runs one script thread per session);
+    a plan serialises its own executions."""
+    key = (int(n), int(n_in), int(batch), int(dtype), int(flags))
+    with _cache_lock:
+        plan = _cache.get(key)
+        if plan is not None:
+            _cache.move_to_end(key)
+            return plan
+    plan = Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags)
+    with _cache_lock:
+        other = _cache.get(key)
+        if other is not None:          # another thread built the same plan meanwhile
+            plan.destroy()
+            return other
+        _cache[key] = plan
+        while len(_cache) > _CACHE_MAX:
+            _, old = _cache.popitem(last=False)
+            old.destroy()
+    return plan
+
+
+def clear_plan_cache():
+    with _cache_lock:
+        while _cache:
+            _, p = _cache.popitem()
+            p.destroy()
+
+
+def engine_dtype(a: np.ndarray):
+    """(library dtype, input is real) for an array, following numpy 2.x promotion:
+    float32 / complex64 stay single precision, everything else runs in double."""
+    if a.dtype == np.complex64:
+        return _lib.C64, False
+    if a.dtype == np.float32 or a.dtype == np.float16:
+        return _lib.C64, True
+    if np.iscomplexobj(a):
+        return _lib.C128, False
+    return _lib.C128, True
+
+
+def fft(a, n=None, axis=-1, norm=None, out=None):
+    """One-dimensional forward DFT along ``axis``, as ``numpy.fft.fft``."""
+    if out is not None:
+        raise NotImplementedError("the `out` argument is not supported")
+    a = np.asarray(a)
+    if a.ndim == 0:
+        raise ValueError("fft requires at least a 1-D array")
+    n_have = a.shape[axis]
+    n = n_have if n is None else int(n)
+    if n < 1:
+        raise ValueError(f"Invalid number of FFT data points ({n}) specified.")
+    if norm not in (None, "backward", "ortho", "forward"):
+        raise ValueError(f'Invalid norm value {norm}; should be "backward", "ortho" or "forward".')
+    dtype, real_in = engine_dtype(a)
+    rdt = np.float32 if dtype == _lib.C64 else np.float64
+    cdt = np.complex64 if dtype == _lib.C64 else np.complex128
+    x = np.moveaxis(a, axis, -1)
+    if n < n_have:
+        x = x[..., :n]                         # numpy crops when n is shorter than the axis
+    n_in = x.shape[-1]
+    lead = x.shape[:-1]
+    batch = int(np.prod(lead)) if lead else 1
+    if batch == 0:
+        return np.moveaxis(np.zeros(lead + (n,), dtype=cdt), -1, axis)
+    x = np.ascontiguousarray(x, dtype=rdt if real_in else cdt).reshape(batch, n_in)
+    scale = {None: 1.0, "backward": 1.0, "ortho": 1.0 / np.sqrt(n), "forward": 1.0 / n}[norm]
+    plan = cached_plan(n, n_in, batch, dtype, _lib.REAL_IN if real_in else 0)
+    y = plan.exec_host(x, scale=scale)
+    return np.moveaxis(y.reshape(lead + (n,)), -1, axis)
+
+
+def fftfreq(n, d=1.0):
+    """Sample frequencies in FFT order: [0, 1, ..., (n-1)//2, -(n//2), ..., -1] / (d*n)."""
+    if not isinstance(n, (int, np.integer)):
+        raise ValueError("n should be an integer")
+    n = int(n)
+    k = np.arange(n, dtype=np.int64)
+    k[(n - 1) // 2 + 1:] -= n
+    return k * (1.0 / (n * d))

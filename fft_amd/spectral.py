@@ -1,0 +1,236 @@
+"""Drop-in replacements for the reference's two spectral estimators.
+
+``fft_from_timeseries``  same signature, return tuple, dtypes, FFT-order axis and
+                         ``ValueError``s as /root/reference/final2.py:115-188
+``fft_extract_E_p``      same as /root/reference/streamlit_app_combined.py:190-251
+
+What runs where.  The window, zero padding, demodulation, forward transform,
+``dt`` scaling, power spectrum and the max / centroid reductions run on the GPU
+as one fused plan (final2.py:139-146, streamlit_app_combined.py:199-215); the
+float64 power spectrum comes back once.  The O(#peaks) tail -- local-maximum
+scan, guard-spaced pick, log-parabolic refinement and the k <= 6 column least
+squares -- stays on the host in numpy, as does the (tiny) eigendecomposition that
+generates f(t) for ``fft_extract_E_p``.
+
+There is no CPU fallback for the transform: without libmfft.so or without a GPU
+these functions raise.
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+from . import _lib
+from .npfft import cached_plan, engine_dtype, fftfreq
+
+TWO_PI = 2.0 * np.pi
+
+
+# --------------------------------------------------------------------------- device part
+
+def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0.0, t0: float = 0.0,
+                   want_spectrum: bool = True):
+    """|dt * FFT_nfft(window * x * exp(i mu t))|^2 on the GPU, in double precision.
+
+    Returns ``(S, smax, ssum, centroid_bins)`` where ``S`` is float64[nfft] (``None``
+    when ``want_spectrum`` is false), ``smax = S.max()``, ``ssum = S.sum()`` and
+    ``centroid_bins = sum(f_k * S)`` with ``f_k`` the signed FFT-order bin index."""
+    x = np.asarray(x)
+    _, real_in = engine_dtype(x)
+    flags = _lib.POWER | _lib.STATS
+    if use_hann:
+        flags |= _lib.HANN
+    if mu != 0.0:
+        flags |= _lib.DEMOD
+    if real_in:
+        flags |= _lib.REAL_IN
+    plan = cached_plan(nfft, x.shape[0], 1, _lib.C128, flags)
+    xin = np.ascontiguousarray(x, dtype=np.float64 if real_in else np.complex128)
+    if want_spectrum:
+        S, stats = plan.exec_host(xin, scale=dt, mu=mu, t0=t0, dt=dt)
+    else:
+        S, stats = None, plan.exec_host(xin, scale=dt, mu=mu, t0=t0, dt=dt, stats_only=True)
+    return S, float(stats[0, 0]), float(stats[0, 1]), float(stats[0, 2])
+
+
+# --------------------------------------------------------------------------- host tail
+
+def _local_maxima(S):
+    """Indices i in [1, len-2] with S[i-1] < S[i] >= S[i+1] (left strict, right weak)."""
+    mid = S[1:-1]
+    return np.flatnonzero((mid > S[:-2]) & (mid >= S[2:])) + 1
+
+
+def _refine_log_parabola(x, y, i):
+    """Vertex of the parabola through (x, log y) at i-1, i, i+1; x[i] at the edges or
+    when the three points are collinear."""
+    if i <= 0 or i >= len(y) - 1:
+        return x[i]
+    l0 = np.log(max(y[i - 1], 1e-300))
+    l1 = np.log(max(y[i], 1e-300))
+    l2 = np.log(max(y[i + 1], 1e-300))
+    curv = 2.0 * (l0 - 2.0 * l1 + l2)
+    if curv == 0:
+        return x[i]
+    return x[i] + ((l0 - l2) / curv) * (0.5 * (x[i + 1] - x[i - 1]))
+
+
+def _window_of(f_t, use_hann):
+    return np.hanning(len(f_t)) if use_hann else np.ones_like(f_t)
+
+
+def _fit_weights(E, times, win, xw):
+    """Least-squares amplitudes of sum_k c_k exp(-i E_k t) * win against xw, clipped
+    to non-negative reals and normalised to sum 1 (when the sum is positive)."""
+    basis = np.exp(-1j * np.outer(times, np.asarray(E, float))) * np.asarray(win)[:, None]
+    coef, *_ = np.linalg.lstsq(basis, xw, rcond=None)
+    p = np.clip(coef.real, 0.0, None)
+    total = p.sum()
+    if total > 0:
+        p = p / total
+    return p, basis, coef
+
+
+# --------------------------------------------------------------------------- estimator A
+
+def fft_from_timeseries(
+    f_t,
+    times,
+    n_levels=3,
+    pad_factor=16,
+    use_hann=True,
+    include_dc=False,
+    dc_guard=1.5,
+    post_prune=True,
+    min_weight=1e-6,
+    keep_top=None,
+    guard_mult=1.2,
+):
+    """Spectral lines (E, p) of a return amplitude f(t); see final2.py:115-188.
+
+    Returns ``(E_hat ascending, p, -omega, S_norm)``; the last two are full-length
+    arrays in FFT order.  With no admissible peak the first two are empty."""
+    times = np.asarray(times, float)
+    f_t = np.asarray(f_t)
+    if times.ndim != 1 or times.size < 2:
+        raise ValueError("`times` must be 1D with length >= 2.")
+    if f_t.shape[0] != times.shape[0]:
+        raise ValueError("`f_t` and `times` must have the same length.")
+    steps = np.diff(times)
+    if not np.allclose(steps, steps[0]):
+        raise ValueError("`times` must be uniformly spaced.")
+    dt = float(steps[0])
+
+    n0 = len(f_t)
+    nfft = int(max(1, pad_factor) * n0)
+    S, smax, _, _ = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann))
+    omega = TWO_PI * fftfreq(nfft, d=dt)
+    S_norm = S / (smax if smax > 0 else 1.0)
+
+    span = times[-1] - times[0]
+    domega = TWO_PI / (span + 1e-12)
+    cand = _local_maxima(S)
+    if include_dc:
+        if S[0] > 0:
+            cand = np.unique(np.concatenate(([0], cand)))
+    else:
+        cand = cand[np.abs(omega[cand]) > dc_guard * domega]
+    if cand.size == 0:
+        return np.array([]), np.array([]), -omega, S_norm
+
+    by_height = cand[np.argsort(S[cand])[::-1]]
+    guard = guard_mult * domega
+    want = max(n_levels, 1)
+    chosen = []
+    for k in by_height:
+        if all(abs(omega[k] - omega[j]) > guard for j in chosen):
+            chosen.append(int(k))
+        if len(chosen) >= want:
+            break
+    E_hat = -np.array([_refine_log_parabola(omega, S, i) for i in chosen])
+
+    win = _window_of(f_t, use_hann)
+    p, _, _ = _fit_weights(E_hat, times, win, f_t * win)
+    if post_prune:
+        keep = p > min_weight
+        E_hat, p = E_hat[keep], p[keep]
+        if keep_top is not None and E_hat.size > keep_top:
+            top = np.argsort(p)[::-1][:keep_top]
+            E_hat, p = E_hat[top], p[top]
+        if p.sum() > 0:
+            p = p / p.sum()
+    order = np.argsort(E_hat)
+    return E_hat[order], p[order], -omega, S_norm
+
+
+# --------------------------------------------------------------------------- estimator B
+
+def return_amplitude(Htop, site, times, hbar=1.0):
+    """f(t) = <site| exp(-i H t / hbar) |site> on the time grid, from the
+    eigendecomposition of the (small, Hermitian) block H
+    (streamlit_app_combined.py:86-93, :166-169)."""
+    H = np.asarray(Htop)
+    w, V = np.linalg.eigh(H)
+    c0 = V[site, :].conj()                        # V^H |site>
+    # Same operation order as evolving the ket and reading its `site` component:
+    # V[site, :] . (exp(-i w t / hbar) * c0).  For an exactly symmetric spectrum f(t) is real
+    # up to rounding, and the +E / -E sign search downstream is decided by that rounding,
+    # so the order of these operations is part of the reference's observable behaviour.
+    phases = np.exp(-1j * np.outer(np.asarray(times, float), w.real) / hbar)
+    return (phases * c0[None, :]) @ V[site, :]
+
+
+def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=True):
+    """(E_est ascending, p_est, omega, S, mu) from f_ss(t) by FFT, optional centroid
+    demodulation and a 2^k sign-search least squares; see
+    streamlit_app_combined.py:190-251."""
+    f_t = return_amplitude(Htop, site=site, times=times)
+    times = np.asarray(times, float)
+    dt = float(times[1] - times[0])
+    win = _window_of(f_t, use_hann)
+    n0 = len(f_t)
+    nfft = int(pad * n0)
+
+    # centroid of the rough spectrum: only two sums come back from the device
+    mu = 0.0
+    if demod:
+        _, _, ssum, centroid_bins = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann),
+                                                   want_spectrum=False)
+        if ssum > 0:
+            mu = float((TWO_PI / (nfft * dt)) * centroid_bins / ssum)
+    xw = f_t * win
+    if demod and mu != 0.0:
+        xw = xw * np.exp(+1j * mu * times)
+
+    S, _, _, _ = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), mu=mu if demod else 0.0,
+                                t0=float(times[0]))
+    omega = TWO_PI * fftfreq(nfft, d=dt)
+
+    cand = _local_maxima(S)
+    if cand.size == 0:
+        return np.array([]), np.array([]), omega, S, mu
+    by_height = cand[np.argsort(S[cand])][::-1]
+    tol = TWO_PI / (times[-1] - times[0] + 1e-12)
+    limit = max(n_peaks * 3, n_peaks)
+    chosen = []
+    for k in by_height:
+        if len(chosen) >= limit:
+            break
+        if all(abs(abs(omega[k]) - abs(omega[j])) > 0.6 * tol for j in chosen):
+            chosen.append(int(k))
+    chosen = sorted(chosen, key=lambda j: S[j], reverse=True)[:n_peaks]
+    if len(chosen) == 0:
+        return np.array([]), np.array([]), omega, S, mu
+    mags = np.sort(np.unique(np.round(np.abs(omega[chosen]), 12)))[:n_peaks]
+
+    best_res, best_E, best_p = np.inf, None, None
+    for signs in itertools.product((-1.0, +1.0), repeat=len(mags)):
+        E_try = np.array([s * m for s, m in zip(signs, mags)])
+        p_try, basis, coef = _fit_weights(E_try, times, win, xw)
+        res = np.linalg.norm(basis @ coef - xw)
+        if res < best_res:
+            best_res, best_E, best_p = res, E_try, p_try
+    E_phys = best_E - mu
+    order = np.argsort(E_phys)
+    return E_phys[order], best_p[order], omega, S, mu

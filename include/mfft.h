@@ -91,7 +91,9 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
               double mu, double t0, double dt, double* d_stats, void* stream);
 
 /* Same transform on host buffers (numpy arrays): copies in, runs, copies out and
- * synchronises.  h_stats: NULL or 3*batch doubles. */
+ * synchronises.  h_stats: NULL or 3*batch doubles.  With MFFT_STATS, h_out may be
+ * NULL: only the statistics come back (the centroid pass of
+ * streamlit_app_combined.py:204-207 needs sum(omega*S)/sum(S), not S itself). */
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale,
                    double mu, double t0, double dt, double* h_stats);
 

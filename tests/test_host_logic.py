@@ -1,0 +1,125 @@
+"""CPU-only checks: the C ABI library loads and exports every declared symbol, the
+product refuses to compute without a GPU, and the host-side tail of the spectral
+estimators (peak scan, refinement, least squares) behaves like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_l2
+from oracle import spectral_oracle as so
+
+
+def test_header_symbols_are_exported_and_bound():
+    from fft_amd import _lib
+    lib = _lib.load()
+    with open(os.path.join(ROOT, "include", "mfft.h")) as fh:
+        header = fh.read()
+    declared = set(re.findall(r"\b(mfft_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mfft_version() >= 100
+    assert lib.mfft_strerror(0) == b"success" and lib.mfft_strerror(-1) == b"invalid argument"
+
+
+def test_flag_values_match_header():
+    from fft_amd import _lib
+    with open(os.path.join(ROOT, "include", "mfft.h")) as fh:
+        header = fh.read()
+    for name in ("HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE"):
+        m = re.search(rf"#define MFFT_{name}\s+(0x[0-9a-fA-F]+)u", header)
+        assert m and int(m.group(1), 16) == getattr(_lib, name)
+    for name in ("C64", "C128"):
+        m = re.search(rf"#define MFFT_{name}\s+(\d+)", header)
+        assert m and int(m.group(1)) == getattr(_lib, name)
+
+
+def _no_gpu():
+    from fft_amd import _lib
+    return _lib.load().mfft_device_count() < 0
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a device every transform raises."""
+    import fft_amd
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(fft_amd.MfftError):
+        fft_amd.fft(np.ones(8))
+    with pytest.raises(fft_amd.MfftError):
+        fft_amd.Plan(1024)
+    t = np.arange(16) * 0.1
+    with pytest.raises(fft_amd.MfftError):
+        fft_amd.fft_from_timeseries(np.ones(16, complex), t)
+
+
+def test_validation_errors_precede_device_use():
+    import json
+    import fft_amd
+    with open(os.path.join(ROOT, "tests", "golden", "errors.json")) as fh:
+        msgs = json.load(fh)
+    cases = {"ndim": (np.ones(4), np.ones((2, 2))), "short": (np.ones(1), np.ones(1)),
+             "len": (np.ones(5), np.arange(4.0)), "uniform": (np.ones(4), np.array([0.0, 1.0, 2.0, 4.0]))}
+    for tag, args in cases.items():
+        with pytest.raises(ValueError) as ei:
+            fft_amd.fft_from_timeseries(*args)
+        assert str(ei.value) == msgs[tag]
+    with pytest.raises(ValueError):
+        fft_amd.fft(np.ones(4), n=0)
+    with pytest.raises(ValueError):
+        fft_amd.fft(np.float64(1.0))
+    with pytest.raises(ValueError):
+        fft_amd.fft(np.ones(4), norm="bogus")
+
+
+@pytest.mark.parametrize("n,d", [(1, 1.0), (2, 0.5), (7, 0.01), (8, 0.01), (24016, 0.01), (256032, 0.01)])
+def test_fftfreq_matches_numpy(n, d):
+    import fft_amd
+    assert np.array_equal(fft_amd.fftfreq(n, d), np.fft.fftfreq(n, d))
+
+
+def test_local_maxima_tie_rule():
+    from fft_amd.spectral import _local_maxima
+    S = np.array([0.0, 1.0, 1.0, 0.5, 2.0, 2.0, 2.0, 0.1, 3.0])
+    # left strict, right weak: of a plateau only its first sample qualifies; the last sample never does
+    ref = np.where((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:]))[0] + 1
+    assert list(_local_maxima(S)) == list(ref) == [1, 4]
+
+
+def test_refine_and_fit_match_oracle():
+    from fft_amd.spectral import _refine_log_parabola, _fit_weights
+    rng = np.random.default_rng(3)
+    y = rng.random(50) + 0.1
+    x = np.linspace(-3, 3, 50)
+    for i in (0, 1, 17, 48, 49):
+        assert _refine_log_parabola(x, y, i) == so._log_parabola(x, y, i)
+    flat = np.ones(5)
+    assert _refine_log_parabola(x[:5], flat, 2) == x[2]
+    t = np.arange(400) * 0.05
+    E = np.array([-1.0, 0.4, 2.2]); p = np.array([0.5, 0.3, 0.2])
+    win = np.hanning(len(t))
+    xw = (p[None, :] * np.exp(-1j * np.outer(t, E))).sum(axis=1) * win
+    got, basis, coef = _fit_weights(E, t, win, xw)
+    np.testing.assert_allclose(got, p, atol=1e-12)
+    assert np.linalg.norm(basis @ coef - xw) < 1e-12
+
+
+def test_return_amplitude_matches_oracle(golden):
+    import fft_amd
+    z = golden("combined_defaults.npz")
+    times = np.arange(0.0, 15.0 + 0.01, 0.01)
+    f = fft_amd.return_amplitude(z["Htop"], 2, times)
+    assert rel_l2(f, z["f_t"]) < 1e-13
+    assert rel_l2(f, so.return_amplitude_top(z["Htop"], 2, times)) < 1e-13
+
+
+def test_engine_dtype_promotion():
+    from fft_amd.npfft import engine_dtype
+    from fft_amd import _lib
+    assert engine_dtype(np.zeros(2, np.complex64)) == (_lib.C64, False)
+    assert engine_dtype(np.zeros(2, np.float32)) == (_lib.C64, True)
+    assert engine_dtype(np.zeros(2, np.complex128)) == (_lib.C128, False)
+    assert engine_dtype(np.zeros(2, np.float64)) == (_lib.C128, True)
+    assert engine_dtype(np.zeros(2, np.int32)) == (_lib.C128, True)
