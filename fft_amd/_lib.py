@@ -21,12 +21,22 @@ OK, E_INVALID, E_UNSUPPORTED, E_NOMEM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4, -5
 # every symbol include/mfft.h declares: (name, restype, argtypes)
 _vp, _i64, _dbl, _int, _u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_uint32
 _dblp = ctypes.POINTER(ctypes.c_double)
+
+
+class Layout(ctypes.Structure):
+    """mfft_layout: element j of signal b sits at
+    b*batch_stride + (seg ? (j // seg)*seg_stride + j % seg : j); zeros = dense."""
+    _fields_ = [("batch_stride", ctypes.c_int64), ("seg", ctypes.c_int64), ("seg_stride", ctypes.c_int64)]
+
+
 SIGNATURES = {
     "mfft_version": (_int, []),
     "mfft_device_count": (_int, []),
     "mfft_strerror": (ctypes.c_char_p, [_int]),
     "mfft_last_error": (ctypes.c_char_p, []),
     "mfft_plan_1d": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32]),
+    "mfft_plan_1d_layout": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32,
+                                   ctypes.POINTER(Layout), ctypes.POINTER(Layout)]),
     "mfft_plan_destroy": (_int, [_vp]),
     "mfft_plan_workspace_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
     "mfft_plan_launches": (_int, [_vp, ctypes.POINTER(_int)]),

@@ -11,6 +11,12 @@
 namespace mfft {
 
 void set_error(const std::string& msg);
+
+// position of element j under a segmented layout (seg == 0: dense)
+__host__ __device__ inline int64_t seg_index(int64_t j, int64_t seg, int64_t seg_stride)
+{
+    return seg > 0 ? (j / seg) * seg_stride + (j % seg) : j;
+}
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define MFFT_HIP(call)                                                        \
@@ -45,6 +51,11 @@ template <typename T> struct KArgs {
     int64_t batch;
     int64_t in_stride;     // elements between consecutive signals in `in`
     int64_t out_stride;    // elements between consecutive spectra in `out`
+    // Segmented layouts (general variants only; seg == 0 means dense): element j of a signal
+    // sits at (j / seg) * seg_stride + (j % seg).  This is how pencil / four-step exchanges
+    // are packed and unpacked inside the transform's own load and store.
+    int64_t in_seg, in_seg_stride;
+    int64_t out_seg, out_seg_stride;
     int n_in;              // samples present per signal (<= N); the rest are zero
     int n_out;             // bins stored per signal (<= N)
     int real_in;           // input elements are real

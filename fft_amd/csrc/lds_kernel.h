@@ -309,8 +309,9 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                 const int j = t + TX * e;
                 C x{0, 0};
                 if (active && j < a.n_in) {
-                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[b * a.in_stride + j];
-                    else x = reinterpret_cast<const C*>(a.in)[b * a.in_stride + j];
+                    const int64_t at = b * a.in_stride + seg_index(j, a.in_seg, a.in_seg_stride);
+                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[at];
+                    else x = reinterpret_cast<const C*>(a.in)[at];
                     if (a.conj_in) x.y = -x.y;
                     if (a.win) { const T w = a.win[j]; x.x *= w; x.y *= w; }
                     if (a.pre) x = cmul(x, a.pre[j]);
@@ -352,8 +353,12 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
             if (active) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
-                    if constexpr (GENERAL) { if (t + TX * e < a.n_out) dst[t + TX * e] = s[e]; }
-                    else st_stream(dst + t + TX * e, s[e]);
+                    if constexpr (GENERAL) {
+                        const int k = t + TX * e;
+                        if (k < a.n_out) dst[seg_index(k, a.out_seg, a.out_seg_stride)] = s[e];
+                    } else {
+                        st_stream(dst + t + TX * e, s[e]);
+                    }
                 }
             }
             if constexpr (VAR == V_GEN_POWER) {
@@ -395,7 +400,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                         const int k = t + TX * e;
                         if (a.conj_out) o.y = -o.y;
                         if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
-                        if (k < a.n_out) dst[k] = o;
+                        if (k < a.n_out) dst[seg_index(k, a.out_seg, a.out_seg_stride)] = o;
                     } else {
                         st_stream(dst + t + TX * e, o);
                     }

@@ -210,6 +210,7 @@ template <typename T> struct Io {
     const void* in = nullptr;
     void* out = nullptr;
     int64_t in_stride = 0, out_stride = 0;
+    int64_t in_seg = 0, in_seg_stride = 0, out_seg = 0, out_seg_stride = 0;
     const T* win = nullptr;
     const cx<T>* pre = nullptr;
     const cx<T>* post = nullptr;
@@ -348,10 +349,13 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.win = io.win; a.pre = io.pre; a.post = io.post; a.stats = io.stats;
         a.batch = batch;
         a.in_stride = io.in_stride; a.out_stride = io.out_stride;
+        a.in_seg = io.in_seg; a.in_seg_stride = io.in_seg_stride;
+        a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
         a.n_in = (int)io.n_in; a.n_out = (int)io.n_out;
         a.real_in = io.real_in; a.conj_in = io.conj_in; a.conj_out = io.conj_out;
         a.scale = io.scale;
-        const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n;
+        const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n &&
+                          io.in_seg == 0 && io.out_seg == 0;
         const bool bare = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && !io.stats && full;
         int variant;
         if (io.power && io.win && bare) variant = V_HANN_POWER;
@@ -382,10 +386,12 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
             a.real_in = io.real_in; a.conj_in = io.conj_in;
+            a.in_seg = io.in_seg; a.in_seg_stride = io.in_seg_stride;
         }
         if (last) {
             a.post = io.post; a.stats = io.stats; a.n_out = io.n_out;
             a.conj_out = io.conj_out; a.scale = io.scale;
+            a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
         }
         const int mode = first ? TM_FIRST : (last ? (io.power ? TM_LAST_POWER : TM_LAST_CPLX) : TM_MID);
         int rc;
@@ -407,6 +413,7 @@ struct Plan {
     uint32_t flags = 0;
     int device = 0;
     enum Kind { ONE_POINT, POW2, CHIRPZ } kind = POW2;
+    mfft_layout lin{0, 0, 0}, lout{0, 0, 0};   // batch_stride 0 = dense default
     Pow2Engine eng;          // length n (POW2) or the padded length m (CHIRPZ)
     int64_t m = 0;           // chirp-z convolution length
     void* d_win = nullptr;   // real window, n_in samples (MFFT_HANN)
@@ -565,7 +572,9 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
 
     if (p->kind == Plan::ONE_POINT) {
         const int64_t blocks = (p->batch + 255) / 256;
-        hipLaunchKernelGGL(n1_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, d_in, d_out, p->batch, p->n_in,
+        if (p->lout.batch_stride > 1) { set_error("1-point plans take dense output only"); return MFFT_E_UNSUPPORTED; }
+        hipLaunchKernelGGL(n1_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, d_in, d_out, p->batch,
+                           p->lin.batch_stride ? p->lin.batch_stride : p->n_in,
                            (p->flags & MFFT_REAL_IN) ? 1 : 0, demod ? (const T*)nullptr : win,
                            demod ? pre : (const cx<T>*)nullptr, (T)scale, inverse ? 1 : 0, power ? 1 : 0, stats);
         MFFT_HIP(hipGetLastError());
@@ -574,7 +583,10 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     if (p->kind == Plan::POW2) {
         Io<T> io;
         io.in = d_in; io.out = d_out;
-        io.in_stride = p->n_in; io.out_stride = p->n;
+        io.in_stride = p->lin.batch_stride ? p->lin.batch_stride : p->n_in;
+        io.out_stride = p->lout.batch_stride ? p->lout.batch_stride : p->n;
+        io.in_seg = p->lin.seg; io.in_seg_stride = p->lin.seg_stride;
+        io.out_seg = p->lout.seg; io.out_seg_stride = p->lout.seg_stride;
         io.win = demod ? nullptr : win;          // with DEMOD the window is folded into pre
         io.pre = demod ? pre : nullptr;
         io.stats = stats;
@@ -589,7 +601,9 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     if (inverse) { set_error("MFFT_INVERSE is implemented for power-of-two lengths only"); return MFFT_E_UNSUPPORTED; }
     Io<T> a;                                        // stage 1: conj(FFT_m(x * pre) ) * conj(FFT_m(b))
     a.in = d_in; a.out = p->d_conv;
-    a.in_stride = p->n_in; a.out_stride = p->m;
+    a.in_stride = p->lin.batch_stride ? p->lin.batch_stride : p->n_in;
+    a.in_seg = p->lin.seg; a.in_seg_stride = p->lin.seg_stride;
+    a.out_stride = p->m;
     a.pre = pre;                                    // window * demod * chirp
     a.post = static_cast<const cx<T>*>(p->d_filt);
     a.n_in = p->n_in; a.n_out = p->m;
@@ -599,7 +613,9 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     if (rc) return rc;
     Io<T> b;                                        // stage 2: conj(FFT_m(.)) / m * c[k], first n bins
     b.in = p->d_conv; b.out = d_out;
-    b.in_stride = p->m; b.out_stride = p->n;
+    b.in_stride = p->m;
+    b.out_stride = p->lout.batch_stride ? p->lout.batch_stride : p->n;
+    b.out_seg = p->lout.seg; b.out_seg_stride = p->lout.seg_stride;
     b.post = static_cast<const cx<T>*>(p->d_chirp);
     b.stats = stats;
     b.n_in = p->m; b.n_out = p->n;
@@ -664,7 +680,16 @@ const char* mfft_strerror(int code)
 
 const char* mfft_last_error(void) { return g_err.c_str(); }
 
-int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags)
+static int layout_ok(const mfft_layout* l, int64_t n)
+{
+    if (!l) return 1;
+    if (l->batch_stride < 0 || l->seg < 0 || l->seg_stride < 0) return 0;
+    if (l->seg > 0 && (l->seg_stride < l->seg || l->seg > n)) return 0;
+    return 1;
+}
+
+int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags,
+                        const mfft_layout* in_layout, const mfft_layout* out_layout)
 {
     if (!out) { set_error("null plan pointer"); return MFFT_E_INVALID; }
     *out = nullptr;
@@ -675,15 +700,23 @@ int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dty
     const uint32_t known = MFFT_HANN | MFFT_POWER | MFFT_DEMOD | MFFT_REAL_IN | MFFT_STATS | MFFT_INVERSE;
     if (flags & ~known) { set_error("unknown flag bits"); return MFFT_E_INVALID; }
     if ((flags & MFFT_STATS) && !(flags & MFFT_POWER)) { set_error("MFFT_STATS needs MFFT_POWER"); return MFFT_E_INVALID; }
+    if (!layout_ok(in_layout, n) || !layout_ok(out_layout, n)) { set_error("bad layout descriptor"); return MFFT_E_INVALID; }
     if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
     Plan* p = new (std::nothrow) Plan;
     if (!p) { set_error("host allocation failed"); return MFFT_E_NOMEM; }
     p->n = n; p->n_in = n_in; p->batch = batch; p->dtype = dtype; p->flags = flags;
+    if (in_layout) p->lin = *in_layout;
+    if (out_layout) p->lout = *out_layout;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("hipGetDevice failed"); return MFFT_E_HIP; }
     const int rc = plan_build(p);
     if (rc != MFFT_OK) { plan_free(p); return rc; }
     *out = reinterpret_cast<mfft_plan>(p);
     return MFFT_OK;
+}
+
+int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags)
+{
+    return mfft_plan_1d_layout(out, n, n_in, batch, dtype, flags, nullptr, nullptr);
 }
 
 int mfft_plan_destroy(mfft_plan plan)
@@ -725,6 +758,10 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     Plan* p = reinterpret_cast<Plan*>(plan);
     if ((p->flags & MFFT_STATS) && !h_stats) { set_error("plan has MFFT_STATS but h_stats is null"); return MFFT_E_INVALID; }
     if (!h_out && !(p->flags & MFFT_STATS)) { set_error("h_out may be null only when the plan returns stats"); return MFFT_E_INVALID; }
+    if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg) {
+        set_error("mfft_exec_host serves dense layouts only; use mfft_exec for strided / segmented plans");
+        return MFFT_E_UNSUPPORTED;
+    }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
     std::lock_guard<std::mutex> lock(p->mu);

@@ -43,6 +43,8 @@ template <typename T> struct TArgs {
     int64_t out_stride;   // elements between signals in `out`
     int64_t n_in;         // FIRST: samples present per signal
     int64_t n_out;        // LAST: bins stored per signal
+    int64_t in_seg, in_seg_stride;     // FIRST: segmented input layout (0 = dense)
+    int64_t out_seg, out_seg_stride;   // LAST: segmented output layout (0 = dense)
     int lb;
     int real_in, conj_in, conj_out;
     T scale;
@@ -122,8 +124,9 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
                 const int64_t idx = j + (int64_t)(t + TX * e) * a.L;   // sample index in the signal
                 C_ x{0, 0};
                 if (idx < a.n_in) {
-                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[b * a.in_stride + idx];
-                    else x = reinterpret_cast<const C_*>(a.in)[b * a.in_stride + idx];
+                    const int64_t at = b * a.in_stride + seg_index(idx, a.in_seg, a.in_seg_stride);
+                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[at];
+                    else x = reinterpret_cast<const C_*>(a.in)[at];
                     if (a.conj_in) x.y = -x.y;
                     if (a.win) { const T wv = a.win[idx]; x.x *= wv; x.y *= wv; }
                     if (a.pre) x = cmul(x, a.pre[idx]);
@@ -192,14 +195,15 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
                 if constexpr (MODE == TM_LAST_POWER) {
                     const T s = o.x * o.x + o.y * o.y;
                     if (k < a.n_out) {
-                        reinterpret_cast<T*>(a.out)[b * a.out_stride + k] = s;
+                        reinterpret_cast<T*>(a.out)[b * a.out_stride + seg_index(k, a.out_seg, a.out_seg_stride)] = s;
                         const double f = (k < (a.n_out + 1) / 2) ? (double)k : (double)(k - a.n_out);
                         mx = (double)s > mx ? (double)s : mx;
                         sm += (double)s;
                         sk += f * (double)s;
                     }
                 } else {
-                    if (k < a.n_out) reinterpret_cast<C_*>(a.out)[b * a.out_stride + k] = o;
+                    if (k < a.n_out)
+                        reinterpret_cast<C_*>(a.out)[b * a.out_stride + seg_index(k, a.out_seg, a.out_seg_stride)] = o;
                 }
             }
             if constexpr (MODE == TM_LAST_POWER) {

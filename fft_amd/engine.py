@@ -29,7 +29,9 @@ class Plan:
     """One batched 1-D transform configuration (see include/mfft.h: mfft_plan_1d)."""
 
     def __init__(self, n: int, n_in: int | None = None, batch: int = 1, dtype: int = _lib.C64,
-                 flags: int = 0):
+                 flags: int = 0, in_layout=None, out_layout=None):
+        """in_layout / out_layout: optional (batch_stride, seg, seg_stride) triples in
+        elements (see mfft_plan_1d_layout); plans with a layout run on device buffers only."""
         lib = _lib.load()
         self.n = int(n)
         self.n_in = self.n if n_in is None else int(n_in)
@@ -37,8 +39,12 @@ class Plan:
         self.dtype = int(dtype)
         self.flags = int(flags)
         self._h = ctypes.c_void_p()
-        _lib.check(lib.mfft_plan_1d(ctypes.byref(self._h), self.n, self.n_in, self.batch,
-                                    self.dtype, self.flags))
+        lin = _lib.Layout(*[int(v) for v in in_layout]) if in_layout is not None else None
+        lout = _lib.Layout(*[int(v) for v in out_layout]) if out_layout is not None else None
+        _lib.check(lib.mfft_plan_1d_layout(ctypes.byref(self._h), self.n, self.n_in, self.batch,
+                                           self.dtype, self.flags,
+                                           ctypes.byref(lin) if lin is not None else None,
+                                           ctypes.byref(lout) if lout is not None else None))
         self._lock = threading.Lock()
 
     # -- introspection ------------------------------------------------------

@@ -73,6 +73,22 @@ const char* mfft_last_error(void);
  * chirp-z (Bluestein) wrapper around the power-of-two kernels.
  */
 int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags);
+
+/* The same plan over strided / segmented device buffers (mfft_exec only).  A layout
+ * says where element j of signal b lives:
+ *     b*batch_stride + (seg ? (j/seg)*seg_stride + j%seg : j)        (in elements)
+ * batch_stride 0 selects the dense default (n_in for input, n for output); seg 0
+ * means the signal is contiguous.  No counterpart in the reference (it never leaves
+ * one process): this is how the multi-GPU decompositions -- np.fft.fft2-style pencils
+ * and the four-step split of one long np.fft.fft (BASELINE configs 4 and 5) -- pack
+ * and unpack their all-to-all exchanges inside the transform's own load and store. */
+typedef struct mfft_layout {
+    int64_t batch_stride;
+    int64_t seg;
+    int64_t seg_stride;
+} mfft_layout;
+int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags,
+                        const mfft_layout* in_layout, const mfft_layout* out_layout);
 int mfft_plan_destroy(mfft_plan plan);
 
 /* Bytes of device workspace the plan holds, and the number of kernel launches

@@ -1,0 +1,111 @@
+"""Helpers for the multi-process tests: a CPU stand-in for the local operations
+(test infrastructure: numpy on CPU tensors, same interface as fft_amd.dist.HipOps)
+and the per-rank worker bodies that torch.multiprocessing spawns."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def layout_index(n, batch, layout, dense_stride):
+    """Flat element positions (batch, n) described by a (batch_stride, seg, seg_stride) layout."""
+    bs, seg, ss = layout if layout is not None else (0, 0, 0)
+    bs = bs or dense_stride
+    j = np.arange(n, dtype=np.int64)
+    within = (j // seg) * ss + (j % seg) if seg else j
+    return np.arange(batch, dtype=np.int64)[:, None] * bs + within[None, :]
+
+
+class NumpyOps:
+    """CPU stand-in: numpy's FFT as the local engine (the oracle's arithmetic)."""
+
+    def empty(self, count, like):
+        import torch
+        return torch.empty(int(count), dtype=like.dtype)
+
+    def fft(self, src, dst, n, batch, in_layout=None, out_layout=None):
+        s, d = src.numpy(), dst.numpy()
+        x = s[layout_index(n, batch, in_layout, n)]
+        d[layout_index(n, batch, out_layout, n)] = np.fft.fft(x, axis=-1)
+
+    def transpose(self, src, dst, rows, cols, batch=1):
+        s = src.numpy()[: batch * rows * cols].reshape(batch, rows, cols)
+        dst.numpy()[: batch * rows * cols] = s.transpose(0, 2, 1).reshape(-1)
+
+    def twiddle(self, x, rows, cols, r0, c0, n_total):
+        v = x.numpy()[: rows * cols].reshape(rows, cols)
+        r = (r0 + np.arange(rows, dtype=np.int64))[:, None]
+        c = (c0 + np.arange(cols, dtype=np.int64))[None, :]
+        v *= np.exp(-2j * np.pi * ((r * c) % n_total) / n_total)
+
+
+def global_inputs(seed, shape, dtype=np.complex128):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((np.asarray(a) - np.asarray(b)).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
+
+
+def worker(rank, world, port, use_gpu, results_dir):
+    """One rank: runs every distributed algorithm and writes its max error to a file."""
+    import torch
+    import torch.distributed as dist
+    from fft_amd import dist as fd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if use_gpu:
+            torch.cuda.set_device(0)                 # rehearsal: every rank shares the one GPU
+            ops, dev = fd.HipOps(), "cuda"
+            tol = 1e-12
+        else:
+            ops, dev = NumpyOps(), "cpu"
+            tol = 1e-12
+        comm = fd.Comm()
+        assert comm.world == world and comm.rank == rank
+        errs = {}
+
+        # ---- 2-D slab -------------------------------------------------------------
+        n0, n1 = 64, 96 if not use_gpu else 128
+        A = global_inputs(1, (n0, n1))
+        F = np.fft.fft2(A)
+        R, W = n0 // world, n1 // world
+        mine = torch.from_numpy(A[rank * R:(rank + 1) * R].reshape(-1).copy()).to(dev)
+        out = fd.fft2_slab(mine, n0, n1, comm, ops, restore_layout=False).cpu().numpy().reshape(W, n0)
+        errs["fft2_T"] = rel_l2(out, F[:, rank * W:(rank + 1) * W].T)
+        out = fd.fft2_slab(mine, n0, n1, comm, ops, restore_layout=True).cpu().numpy().reshape(R, n1)
+        errs["fft2_N"] = rel_l2(out, F[rank * R:(rank + 1) * R])
+
+        # ---- 1-D four-step ---------------------------------------------------------
+        n1f, n2f = 32, 64
+        n = n1f * n2f
+        x = global_inputs(2, (n,))
+        X = np.fft.fft(x)
+        chunk = n // world
+        mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
+        out = fd.fft1d_fourstep(mine, n1f, n2f, comm, ops, natural_order=True).cpu().numpy()
+        errs["fft1d_N"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
+        out = fd.fft1d_fourstep(mine, n1f, n2f, comm, ops, natural_order=False).cpu().numpy()
+        R1 = n1f // world
+        want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
+        errs["fft1d_T"] = rel_l2(out.reshape(R1, n2f), want)
+
+        # ---- batch sharding: no collective ------------------------------------------
+        lo, hi = fd.shard_range(37, world, rank)
+        sizes = [fd.shard_range(37, world, r) for r in range(world)]
+        assert sizes[0][0] == 0 and sizes[-1][1] == 37 and all(a[1] == b[0] for a, b in zip(sizes, sizes[1:]))
+        errs["shard"] = 0.0 if (hi - lo) in (37 // world, 37 // world + 1) else 1.0
+
+        bad = {k: v for k, v in errs.items() if not v < tol}
+        with open(os.path.join(results_dir, f"rank{rank}.txt"), "w") as fh:
+            fh.write("OK" if not bad else f"FAIL {bad}")
+    finally:
+        dist.destroy_process_group()
