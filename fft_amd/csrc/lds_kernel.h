@@ -446,7 +446,9 @@ template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_f
     return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>) + table_lds_bytes<T, typename SC::RD, TX, SC::P, VAR>();
 }
 
-int pick_grid(const void* kernel, int block, size_t lds, int64_t groups);
+// persistent grid: resident workgroups per CU (queried once per kernel) x CUs, capped by the work
+int blocks_per_cu(const void* kernel, int block, size_t lds);
+int pick_grid(int per_cu, int64_t groups);
 
 template <typename T, int LOG2N, int VAR>
 int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
@@ -456,17 +458,18 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
     constexpr int SLOTS = BLOCK / BlockCfg<LOG2N>::TX;
     constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0;
     auto kern = fft_lds_kernel<T, SC::P, typename SC::RD, kPadShift, BLOCK, VAR>;
-    static thread_local int attr_dev = -1;
+    static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
     if (attr_dev != dev) {
         MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        per_cu = blocks_per_cu(reinterpret_cast<const void*>(kern), BLOCK, lds);
         attr_dev = dev;
     }
     const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
     if (groups <= 0) return MFFT_OK;
-    if (grid <= 0) grid = pick_grid(reinterpret_cast<const void*>(kern), BLOCK, lds, groups);
+    if (grid <= 0) grid = pick_grid(per_cu, groups);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;

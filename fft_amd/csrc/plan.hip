@@ -85,11 +85,16 @@ int device_cu_count()
     return cached;
 }
 
-int pick_grid(const void* kernel, int block, size_t lds, int64_t groups)
+int blocks_per_cu(const void* kernel, int block, size_t lds)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
+    return per_cu;
+}
+
+int pick_grid(int per_cu, int64_t groups)
+{
     int64_t g = (int64_t)per_cu * device_cu_count();
     if (g > groups) g = groups;
     if (g < 1) g = 1;
@@ -380,6 +385,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.tw_hi = static_cast<const cx<T>*>(gp.d_hi);
         a.L = n >> gp.log2g;
         a.NS = gp.ns;
+        a.log2_ns = ilog2(gp.ns);
+        a.log2_tiles = log2n - gp.log2g - (sizeof(T) == 4 ? tile_log2c_c64() : tile_log2c_c128());
         a.batch = batch;
         a.lb = gp.lb;
         a.scale = 1;

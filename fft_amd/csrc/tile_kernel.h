@@ -46,6 +46,8 @@ template <typename T> struct TArgs {
     int64_t in_seg, in_seg_stride;     // FIRST: segmented input layout (0 = dense)
     int64_t out_seg, out_seg_stride;   // LAST: segmented output layout (0 = dense)
     int lb;
+    int log2_ns;          // NS = 1 << log2_ns
+    int log2_tiles;       // tiles per signal = (L / C) = 1 << log2_tiles
     int real_in, conj_in, conj_out;
     T scale;
 };
@@ -109,11 +111,12 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
     }
     (void)LO_MAX;
 
-    const int64_t tiles_per_signal = a.L / C;
-    const int64_t total = tiles_per_signal * a.batch;
+    // NS, L and the tile count are powers of two: shifts and masks, no 64-bit division
+    const int64_t total = a.batch << a.log2_tiles;
+    const int64_t ns_mask = a.NS - 1;
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
-        const int64_t b = w / tiles_per_signal;
-        const int64_t j0 = (w - b * tiles_per_signal) * C;
+        const int64_t b = w >> a.log2_tiles;
+        const int64_t j0 = (w & ((int64_t(1) << a.log2_tiles) - 1)) * C;
         const int64_t j = j0 + c;
         C_ v[P];
 
@@ -135,19 +138,22 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             }
         } else {
             const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
-            const int64_t m = j % a.NS;
+            const uint32_t m = (uint32_t)(j & ns_mask);           // NS <= 2^30
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = src[(int64_t)(t + TX * e) * a.L];
+#if !MFFT_DIAG_NOFFT
 #pragma unroll
             for (int e = 0; e < P; ++e) {
-                const int64_t k = m * (int64_t)(t + TX * e);
-                const C_ wl = lo[k & ((1 << a.lb) - 1)];
+                const uint64_t k = (uint64_t)m * (uint32_t)(t + TX * e);   // < NS*G, one 32x32->64 multiply
+                const C_ wl = lo[(uint32_t)k & ((1u << a.lb) - 1)];
                 const C_ wh = a.tw_hi[k >> a.lb];
                 v[e] = cmul(v[e], cmul(wl, wh));
             }
+#endif
         }
 
         // ---- G-point DFT of every column, in LDS -----------------------------------
+#if !MFFT_DIAG_NOFFT
         pass_compute<T, RD, 0, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
         if constexpr (NPASS > 1) {
             tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
@@ -161,6 +167,7 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
             pass_compute<T, RD, 3, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
         }
+#endif
         // v[e] = output q = t + TX*e of column c
 
         // ---- store -------------------------------------------------------------------
@@ -179,8 +186,8 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
                 dst[r] = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
             }
         } else if constexpr (MODE == TM_MID) {
-            const int64_t m = j % a.NS;
-            C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + (j / a.NS) * a.NS * G + m;
+            const int64_t m = j & ns_mask;
+            C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + ((j >> a.log2_ns) << a.log2_ns) * G + m;
 #pragma unroll
             for (int e = 0; e < P; ++e) dst[(int64_t)(t + TX * e) * a.NS] = v[e];
         } else {
@@ -242,17 +249,18 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
     static_assert(BLOCK <= 1024, "tile workgroup too large");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     auto kern = fft_tile_kernel<T, LOG2G, LOG2C, MODE>;
-    static thread_local int attr_dev = -1;
+    static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
     if (attr_dev != dev) {
         MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        per_cu = blocks_per_cu(reinterpret_cast<const void*>(kern), BLOCK, lds);
         attr_dev = dev;
     }
-    const int64_t total = (a.L >> LOG2C) * a.batch;
+    const int64_t total = a.batch << a.log2_tiles;
     if (total <= 0) return MFFT_OK;
-    const int grid = pick_grid(reinterpret_cast<const void*>(kern), BLOCK, lds, total);
+    const int grid = pick_grid(per_cu, total);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
