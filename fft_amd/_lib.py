@@ -54,6 +54,35 @@ class MfftError(RuntimeError):
     """A libmfft call failed for a reason other than a bad argument."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (soname
+    libamdhip64.so.7) and finds it by file name; libmfft.so asks for the soname and would
+    otherwise bring in /opt/rocm's copy.  Two runtimes in one process cannot both own the
+    device ("No HIP GPUs are available" from whichever comes second), so when torch is
+    installed its runtime is loaded first -- without importing torch -- and libmfft.so binds
+    to it through the shared soname.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                      # torch already loaded its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for base in spec.submodule_search_locations:
+        libdir = os.path.join(base, "lib")
+        hip = os.path.join(libdir, "libamdhip64.so")
+        if os.path.exists(hip):
+            for dep in ("libhsa-runtime64.so",):
+                p = os.path.join(libdir, dep)
+                if os.path.exists(p):
+                    ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+            ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+            return
+
+
 def load():
     """Load libmfft.so (once) and attach the prototypes.  Raises if it is not built."""
     global _lib
@@ -62,6 +91,7 @@ def load():
             raise MfftError(
                 f"{LIB_PATH} is missing: build it with `make -C fft_amd/csrc` "
                 "(there is no CPU fallback for the spectral path)")
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

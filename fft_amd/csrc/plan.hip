@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -256,7 +257,7 @@ struct GlobalPass {
     int64_t ns = 1;          // product of earlier radices
     int lb = 0;              // low-table bits
     void* d_tw = nullptr;    // inner tables of the G-point DFT
-    void* d_lo = nullptr;    // exp(-2 pi i k / M), k < 2^lb           (ns > 1 only)
+    void* d_lo = nullptr;    // exp(-2 pi i k / M), k < 2^lb           (ns > 1 only; always double)
     void* d_hi = nullptr;    // exp(-2 pi i (k << lb) / M), k < M >> lb
 };
 
@@ -276,6 +277,43 @@ struct Pow2Engine {
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
 };
 
+static int tile_log2c(int dtype, int log2g)
+{
+    return dtype == MFFT_C64 ? tile_log2c_c64(log2g) : tile_log2c_c128(log2g);
+}
+
+// How a length above one LDS residency is split into global passes (log2 of each radix, first
+// pass first).  Fewest passes first; within that the radices are balanced, larger ones first.
+// MFFT_SPLIT="8,8,8" overrides the choice (tuning aid; must multiply to the length).
+static int choose_split(int log2n, int dtype, std::vector<int>* out)
+{
+    out->clear();
+    if (const char* env = getenv("MFFT_SPLIT")) {
+        int sum = 0;
+        for (const char* p = env; *p;) {
+            const int v = (int)strtol(p, const_cast<char**>(&p), 10);
+            if (v < kTileMinLog2G || v > kTileMaxLog2G) break;
+            out->push_back(v);
+            sum += v;
+            if (*p == ',') ++p;
+        }
+        if (sum == log2n && out->size() >= 2 && out->size() <= 4) return MFFT_OK;
+        out->clear();
+    }
+    const int maxg = kTileMaxLog2G;
+    const int npass = (log2n + maxg - 1) / maxg;
+    if (npass > 4) { set_error("length above the four-pass range"); return MFFT_E_UNSUPPORTED; }
+    for (int s = 0; s < npass; ++s) out->push_back(log2n / npass + (s < log2n % npass ? 1 : 0));
+    for (size_t s = 0; s < out->size(); ++s) {
+        const int g = (*out)[s];
+        if (g < kTileMinLog2G) { set_error("tile radix too small"); return MFFT_E_UNSUPPORTED; }
+        // later passes need NS >= columns per tile; the tile count L/C must be >= 1
+        if (log2n - g < tile_log2c(dtype, g)) { set_error("tile wider than the pass"); return MFFT_E_UNSUPPORTED; }
+    }
+    if (out->size() >= 2 && (*out)[0] < tile_log2c(dtype, (*out)[1])) { set_error("first radix below tile width"); return MFFT_E_UNSUPPORTED; }
+    return MFFT_OK;
+}
+
 int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
 {
     n = n_; batch = batch_; dtype = dtype_;
@@ -291,15 +329,14 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
         return upload_complex_dt(dtype, re, im, &d_tw);
     }
     single = false;
-    const int log2c = dtype == MFFT_C64 ? tile_log2c_c64() : tile_log2c_c128();
-    const int npass = (log2n + kTileMaxLog2G - 1) / kTileMaxLog2G;
-    if (npass > 4) { set_error("length above 2^40"); return MFFT_E_UNSUPPORTED; }
-    // split log2n as evenly as possible, larger radices first
+    std::vector<int> split;
+    int rc0 = choose_split(log2n, dtype, &split);
+    if (rc0) return rc0;
+    const int npass = (int)split.size();
     int64_t ns = 1;
     for (int s = 0; s < npass; ++s) {
         GlobalPass gp;
-        gp.log2g = log2n / npass + (s < log2n % npass ? 1 : 0);
-        if (gp.log2g < kTileMinLog2G || gp.log2g < log2c) { set_error("tile radix too small"); return MFFT_E_UNSUPPORTED; }
+        gp.log2g = split[(size_t)s];
         gp.ns = ns;
         LdsGeometry g{};
         if (!lds_geometry(dtype, gp.log2g, &g)) { set_error("no geometry for tile radix"); return MFFT_E_UNSUPPORTED; }
@@ -314,19 +351,19 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
             const int64_t lo_n = int64_t(1) << gp.lb, hi_n = m >> gp.lb;
             re.resize((size_t)lo_n); im.resize((size_t)lo_n);
             for (int64_t k = 0; k < lo_n; ++k) unit_root(k, m, &re[(size_t)k], &im[(size_t)k]);
-            rc = upload_complex_dt(dtype, re, im, &gp.d_lo);
+            rc = upload_complex<double>(re, im, &gp.d_lo);
             if (rc) { passes.push_back(gp); return rc; }
             re.resize((size_t)hi_n); im.resize((size_t)hi_n);
             for (int64_t k = 0; k < hi_n; ++k) unit_root(k << gp.lb, m, &re[(size_t)k], &im[(size_t)k]);
-            rc = upload_complex_dt(dtype, re, im, &gp.d_hi);
+            rc = upload_complex<double>(re, im, &gp.d_hi);
             if (rc) { passes.push_back(gp); return rc; }
-            bytes += (lo_n + hi_n) * 2 * (int64_t)real_size(dtype);
+            bytes += (lo_n + hi_n) * 2 * (int64_t)sizeof(double);
         }
         passes.push_back(gp);
         ns <<= gp.log2g;
     }
     const size_t wbytes = (size_t)n * (size_t)batch * 2 * real_size(dtype);
-    const int nwork = npass > 2 ? 2 : 1;
+    const int nwork = passes.size() > 2 ? 2 : 1;
     for (int i = 0; i < nwork; ++i) {
         MFFT_HIP(hipMalloc(&work[i], wbytes));
         bytes += (int64_t)wbytes;
@@ -381,12 +418,12 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.out = last ? io.out : work[p & 1];
         a.out_stride = last ? io.out_stride : n;
         a.tw = static_cast<const cx<T>*>(gp.d_tw);
-        a.tw_lo = static_cast<const cx<T>*>(gp.d_lo);
-        a.tw_hi = static_cast<const cx<T>*>(gp.d_hi);
+        a.tw_lo = static_cast<const cx<double>*>(gp.d_lo);
+        a.tw_hi = static_cast<const cx<double>*>(gp.d_hi);
         a.L = n >> gp.log2g;
         a.NS = gp.ns;
         a.log2_ns = ilog2(gp.ns);
-        a.log2_tiles = log2n - gp.log2g - (sizeof(T) == 4 ? tile_log2c_c64() : tile_log2c_c128());
+        a.log2_tiles = log2n - gp.log2g - tile_log2c(dtype, gp.log2g);
         a.batch = batch;
         a.lb = gp.lb;
         a.scale = 1;
@@ -400,7 +437,11 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.conj_out = io.conj_out; a.scale = io.scale;
             a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
         }
-        const int mode = first ? TM_FIRST : (last ? (io.power ? TM_LAST_POWER : TM_LAST_CPLX) : TM_MID);
+        const bool in_plain = !io.win && !io.pre && !io.real_in && !io.conj_in && io.n_in == n && io.in_seg == 0;
+        const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 &&
+                               io.scale == (T)1 && !io.power;
+        const int mode = first ? (in_plain ? TM_FIRST_PLAIN : TM_FIRST_GEN)
+                               : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
         int rc;
         if constexpr (sizeof(T) == 4) rc = launch_tile_c64(gp.log2g, mode, a, s);
         else rc = launch_tile_c128(gp.log2g, mode, a, s);

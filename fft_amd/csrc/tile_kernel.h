@@ -19,8 +19,11 @@
 // is [position][column] with an odd pitch so that both "lanes along a row" and
 // "lanes down a column" are conflict-free.
 //
-// The twiddle exp(-2*pi*i*k/M), k = (j mod NS)*i < M = NS*G, comes from a two-level
-// table: low 2^LB entries staged in LDS, high M/2^LB entries read through L2.
+// The twiddle exp(-2*pi*i*k/M), k = (j mod NS)*i < M = NS*G, is built per thread from four
+// table reads: with m = j mod NS and rows i = t + TX*e, w_e = W^(m*t) * (W^(m*TX))^e.  Base and
+// step each come from a two-level double-precision table (low 2^LB entries, high M/2^LB
+// entries, both L2-resident) and the recurrence runs in double for both precisions, so its
+// rounding stays far below the complex64 / complex128 tolerances.
 #pragma once
 #include "lds_kernel.h"
 
@@ -30,8 +33,8 @@ template <typename T> struct TArgs {
     const void* in;
     void* out;
     const cx<T>* tw;      // inner per-pass tables for the G-point DFT
-    const cx<T>* tw_lo;   // exp(-2*pi*i*k/M),        k < 2^lb
-    const cx<T>* tw_hi;   // exp(-2*pi*i*(k<<lb)/M),  k < M >> lb
+    const cx<double>* tw_lo;   // exp(-2*pi*i*k/M),        k < 2^lb      (double for both precisions)
+    const cx<double>* tw_hi;   // exp(-2*pi*i*(k<<lb)/M),  k < M >> lb
     const T* win;         // FIRST: real window over the n_in input samples, or nullptr
     const cx<T>* pre;     // FIRST: complex premultiplier, or nullptr
     const cx<T>* post;    // LAST: complex postmultiplier over the n_out bins, or nullptr
@@ -52,7 +55,19 @@ template <typename T> struct TArgs {
     T scale;
 };
 
-enum TileMode { TM_MID = 0, TM_FIRST = 1, TM_LAST_CPLX = 2, TM_LAST_POWER = 3 };
+// MID: plain strided in / strided out.  FIRST_*: sample order in, contiguous runs out, no
+// inter-pass twiddle.  LAST_*: natural-order bins out.  *_PLAIN = dense full-length complex
+// data and nothing fused; *_GEN / LAST_POWER carry the runtime prologue / epilogue.
+enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN = 3, TM_LAST_GEN = 4,
+                TM_LAST_POWER = 5 };
+
+// Columns per tile: 256-byte rows where LDS allows (32 complex64 / 16 complex128 up to 256-point
+// columns), 128-byte rows for the 512-point tile (the largest: a 1024-point tile would need 1024
+// threads at <= 128 VGPRs for complex64, which spills, or more than 160 KiB for complex128).  Measured on MI355X, a G x run
+// strided copy moves 4.4-5.0 TB/s at 128-B runs and 5.0-5.3 TB/s at 256-B runs.
+template <typename T, int LOG2G> struct TileCols {
+    static constexpr int LOG2C = (sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0);
+};
 
 template <int LOG2G> struct TileCfg {
     using SC = SizeCfg<LOG2G>;
@@ -87,6 +102,8 @@ __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>
 template <typename T, int LOG2G, int LOG2C, int MODE>
 __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel(const TArgs<T> a)
 {
+    constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN);
+    constexpr bool LAST = (MODE == TM_LAST_PLAIN || MODE == TM_LAST_GEN || MODE == TM_LAST_POWER);
     using C_ = cx<T>;
     using TC = TileCfg<LOG2G>;
     using RD = typename TC::SC::RD;
@@ -97,19 +114,15 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
     constexpr int PADSHIFT = kPadShift;
     constexpr int NPASS = RD::npass;
     constexpr int LDS_ELEMS = (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
-    constexpr int LO_MAX = 256;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
-    C_* lo = lds + LDS_ELEMS;                 // low twiddle table (MODE != FIRST)
+    C_* twl = lds + LDS_ELEMS;                // per-pass tables of the G-point DFT
 
     const int c = threadIdx.x % C;            // column of the tile = lane-fastest
     const int t = threadIdx.x / C;            // thread within the column's DFT
-    if constexpr (MODE != TM_FIRST) {
-        for (int i = threadIdx.x; i < (1 << a.lb); i += BLOCK) lo[i] = a.tw_lo[i];
-        __syncthreads();
-    }
-    (void)LO_MAX;
+    for (int i = threadIdx.x; i < tw_total_elems<RD>(); i += BLOCK) twl[i] = a.tw[i];
+    __syncthreads();
 
     // NS, L and the tile count are powers of two: shifts and masks, no 64-bit division
     const int64_t total = a.batch << a.log2_tiles;
@@ -121,7 +134,12 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
         C_ v[P];
 
         // ---- load the G x C tile (row i = t + TX*e, column c) --------------------
-        if constexpr (MODE == TM_FIRST) {
+        if constexpr (MODE == TM_FIRST_PLAIN) {
+            const C_* __restrict__ p = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j + (int64_t)t * a.L;
+            const int64_t pstep = (int64_t)TX * a.L;
+#pragma unroll
+            for (int e = 0; e < P; ++e) { v[e] = *p; p += pstep; }
+        } else if constexpr (MODE == TM_FIRST_GEN) {
 #pragma unroll
             for (int e = 0; e < P; ++e) {
                 const int64_t idx = j + (int64_t)(t + TX * e) * a.L;   // sample index in the signal
@@ -139,39 +157,47 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
         } else {
             const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
             const uint32_t m = (uint32_t)(j & ns_mask);           // NS <= 2^30
+            const C_* __restrict__ p = src + (int64_t)t * a.L;
+            const int64_t pstep = (int64_t)TX * a.L;
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = src[(int64_t)(t + TX * e) * a.L];
+            for (int e = 0; e < P; ++e) { v[e] = *p; p += pstep; }
 #if !MFFT_DIAG_NOFFT
+            const uint32_t lomask = (1u << a.lb) - 1;
+            const uint64_t kb = (uint64_t)m * (uint32_t)t;        // base exponent  m*t      < NS*G
+            const uint64_t ks = (uint64_t)m * (uint32_t)TX;       // step exponent  m*TX     < NS*G
+            const cx<double> bl = a.tw_lo[(uint32_t)kb & lomask], bh = a.tw_hi[kb >> a.lb];
+            const cx<double> sl = a.tw_lo[(uint32_t)ks & lomask], sh = a.tw_hi[ks >> a.lb];
+            cx<double> w = cmul(bl, bh);
+            const cx<double> step = cmul(sl, sh);
 #pragma unroll
             for (int e = 0; e < P; ++e) {
-                const uint64_t k = (uint64_t)m * (uint32_t)(t + TX * e);   // < NS*G, one 32x32->64 multiply
-                const C_ wl = lo[(uint32_t)k & ((1u << a.lb) - 1)];
-                const C_ wh = a.tw_hi[k >> a.lb];
-                v[e] = cmul(v[e], cmul(wl, wh));
+                const double xr = (double)v[e].x, xi = (double)v[e].y;
+                v[e] = C_{(T)(xr * w.x - xi * w.y), (T)(xr * w.y + xi * w.x)};
+                w = cmul(w, step);
             }
 #endif
         }
 
         // ---- G-point DFT of every column, in LDS -----------------------------------
 #if !MFFT_DIAG_NOFFT
-        pass_compute<T, RD, 0, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+        pass_compute<T, RD, 0, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
         if constexpr (NPASS > 1) {
             tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 1, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+            pass_compute<T, RD, 1, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 2) {
             tile_exchange<T, RD, 1, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 2, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+            pass_compute<T, RD, 2, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 3) {
             tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 3, P, TX, TW_GLOBAL>(v, t, a.tw, nullptr, nullptr);
+            pass_compute<T, RD, 3, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
         }
 #endif
         // v[e] = output q = t + TX*e of column c
 
         // ---- store -------------------------------------------------------------------
-        if constexpr (MODE == TM_FIRST) {
+        if constexpr (FIRST) {
             // NS = 1: y[(j0 + c)*G + q] -- the tile is one contiguous run of C*G elements,
             // q fastest.  Turn the registers through LDS so that lanes run along q.
             __syncthreads();
@@ -187,11 +213,18 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             }
         } else if constexpr (MODE == TM_MID) {
             const int64_t m = j & ns_mask;
-            C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + ((j >> a.log2_ns) << a.log2_ns) * G + m;
+            C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride +
+                                 ((j >> a.log2_ns) << a.log2_ns) * G + m + (int64_t)t * a.NS;
+            const int64_t qstep = (int64_t)TX * a.NS;
 #pragma unroll
-            for (int e = 0; e < P; ++e) dst[(int64_t)(t + TX * e) * a.NS] = v[e];
-        } else {
+            for (int e = 0; e < P; ++e) { *q = v[e]; q += qstep; }
+        } else if constexpr (MODE == TM_LAST_PLAIN) {
             // last pass: NS*G = N, so j < NS and bin k = j + q*NS
+            C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j + (int64_t)t * a.NS;
+            const int64_t qstep = (int64_t)TX * a.NS;
+#pragma unroll
+            for (int e = 0; e < P; ++e) { *q = v[e]; q += qstep; }
+        } else {
             double mx = 0.0, sm = 0.0, sk = 0.0;
 #pragma unroll
             for (int e = 0; e < P; ++e) {
@@ -238,7 +271,8 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
 template <typename T, int LOG2G, int LOG2C> constexpr size_t tile_lds_bytes()
 {
     constexpr int G = 1 << LOG2G, C = 1 << LOG2C;
-    return ((size_t)(lds_pad<kPadShift>(G - 1) + 1) * (C + 1) + 256) * sizeof(cx<T>);
+    using RD = typename TileCfg<LOG2G>::SC::RD;
+    return ((size_t)(lds_pad<kPadShift>(G - 1) + 1) * (C + 1) + (size_t)tw_total_elems<RD>()) * sizeof(cx<T>);
 }
 
 template <typename T, int LOG2G, int LOG2C, int MODE>
@@ -266,38 +300,48 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
     return MFFT_OK;
 }
 
-template <typename T, int LOG2G, int LOG2C>
+template <typename T, int LOG2G>
 int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
 {
+    constexpr int LC = TileCols<T, LOG2G>::LOG2C;
     switch (mode) {
-    case TM_MID: return launch_tile_one<T, LOG2G, LOG2C, TM_MID>(a, s);
-    case TM_FIRST: return launch_tile_one<T, LOG2G, LOG2C, TM_FIRST>(a, s);
-    case TM_LAST_CPLX: return launch_tile_one<T, LOG2G, LOG2C, TM_LAST_CPLX>(a, s);
-    case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LOG2C, TM_LAST_POWER>(a, s);
+    case TM_MID: return launch_tile_one<T, LOG2G, LC, TM_MID>(a, s);
+    case TM_FIRST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_PLAIN>(a, s);
+    case TM_FIRST_GEN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_GEN>(a, s);
+    case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_LAST_PLAIN>(a, s);
+    case TM_LAST_GEN: return launch_tile_one<T, LOG2G, LC, TM_LAST_GEN>(a, s);
+    case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LC, TM_LAST_POWER>(a, s);
     }
     set_error("unknown tile mode");
     return MFFT_E_INVALID;
 }
 
-// Column count per tile: 16 complex64 (128-B rows); complex128 uses 8 (128-B rows),
-// which is also what keeps the 1024-point tile inside 160 KiB.
-template <typename T> struct TileCols { static constexpr int LOG2C = sizeof(T) == 4 ? 4 : 3; };
-
 template <typename T>
 int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
 {
-    constexpr int LC = TileCols<T>::LOG2C;
     switch (log2g) {
-    case 4: return launch_tile_mode<T, 4, LC>(mode, a, s);
-    case 5: return launch_tile_mode<T, 5, LC>(mode, a, s);
-    case 6: return launch_tile_mode<T, 6, LC>(mode, a, s);
-    case 7: return launch_tile_mode<T, 7, LC>(mode, a, s);
-    case 8: return launch_tile_mode<T, 8, LC>(mode, a, s);
-    case 9: return launch_tile_mode<T, 9, LC>(mode, a, s);
-    case 10: return launch_tile_mode<T, 10, LC>(mode, a, s);
+    case 4: return launch_tile_mode<T, 4>(mode, a, s);
+    case 5: return launch_tile_mode<T, 5>(mode, a, s);
+    case 6: return launch_tile_mode<T, 6>(mode, a, s);
+    case 7: return launch_tile_mode<T, 7>(mode, a, s);
+    case 8: return launch_tile_mode<T, 8>(mode, a, s);
+    case 9: return launch_tile_mode<T, 9>(mode, a, s);
     }
-    set_error("tile radix outside 16..1024");
+    set_error("tile radix outside 16..512");
     return MFFT_E_UNSUPPORTED;
+}
+
+template <typename T> int tile_log2c_for(int log2g)
+{
+    switch (log2g) {
+    case 4: return TileCols<T, 4>::LOG2C;
+    case 5: return TileCols<T, 5>::LOG2C;
+    case 6: return TileCols<T, 6>::LOG2C;
+    case 7: return TileCols<T, 7>::LOG2C;
+    case 8: return TileCols<T, 8>::LOG2C;
+    case 9: return TileCols<T, 9>::LOG2C;
+    }
+    return 0;
 }
 
 }  // namespace mfft
