@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--n", type=int, default=N_POINTS, help="transform length (default: the headline 1024)")
     ap.add_argument("--batch", type=int, default=BATCH, help="signals per GPU (default: the headline 65536)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="all ranks share cuda:0 (use with --backend gloo on a one-GPU box; not a measurement)")
     return ap.parse_args()
 
 
@@ -87,12 +90,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if args.rehearse_one_gpu else local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend)
     n, batch = args.n, args.batch
     log2n = int(round(math.log2(n)))
     assert 1 << log2n == n, "bench workload is a power-of-two length"

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The reference apps' own call shapes on the GPU path vs the numpy path, same host.
+
+    python tools/app_bench.py
+
+final2 defaults: N0 = 8001 -> Nfft = 256032 (pad 32); combined defaults: N0 = 1501 -> 24016."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fft_amd  # noqa: E402
+from oracle import spectral_oracle as so  # noqa: E402  (CPU path timed beside, checker only)
+
+
+def best(f, reps=5):
+    b = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        f()
+        b = min(b, time.perf_counter() - t0)
+    return b
+
+
+def main():
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n0, pad in ((8001, 32), (1501, 16), (8001, 64)):
+        nfft = n0 * pad
+        dt = 0.01
+        times = np.arange(n0) * dt
+        f_t = so.return_amplitude_block([1, 1, 1], [1, 1], 1, 0, times)
+        # device-resident plan
+        plan = fft_amd.Plan(nfft, n_in=n0, dtype=fft_amd.C128, flags=fft_amd.HANN | fft_amd.POWER | fft_amd.STATS)
+        d_x = torch.from_numpy(f_t).cuda()
+        d_s = torch.empty(nfft, dtype=torch.float64, device="cuda")
+        d_st = torch.zeros(3, dtype=torch.float64, device="cuda")
+        for _ in range(20):
+            plan.exec(d_x, d_s, scale=dt, d_stats=d_st, stream=stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            plan.exec(d_x, d_s, scale=dt, d_stats=d_st, stream=stream)
+        e1.record(); e1.synchronize()
+        t_dev = e0.elapsed_time(e1) / 50 * 1e-3
+        t_host = best(lambda: plan.exec_host(f_t, scale=dt))
+        kw = dict(n_levels=3, pad_factor=pad, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=3)
+        fft_amd.fft_from_timeseries(f_t, times, **kw)
+        t_full = best(lambda: fft_amd.fft_from_timeseries(f_t, times, **kw))
+        t_ref_fft = best(lambda: np.abs(dt * np.fft.fft(f_t * np.hanning(n0), n=nfft)) ** 2)
+        t_ref_full = best(lambda: so.fft_from_timeseries(f_t, times, **kw), reps=3)
+        print(f"N0={n0} Nfft={nfft} launches={plan.launches}: "
+              f"device plan {t_dev*1e6:8.1f} us | exec_host {t_host*1e3:7.3f} ms | "
+              f"fft_from_timeseries GPU path {t_full*1e3:7.2f} ms vs numpy path {t_ref_full*1e3:7.2f} ms "
+              f"(numpy window+fft+power alone {t_ref_fft*1e3:7.2f} ms)", flush=True)
+        plan.destroy()
+
+
+if __name__ == "__main__":
+    main()
