@@ -76,6 +76,7 @@ enum Variant {
 // Description of how one power-of-two length is decomposed inside the LDS kernel.
 struct LdsGeometry {
     int n, p, tx, block, slots, npass, radix[4];
+    int split16;           // radix-16 passes store six twiddle generators instead of fifteen powers
     size_t lds_bytes;
     size_t tw_elems;       // total twiddle-table entries
 };

@@ -19,6 +19,7 @@ template <int L> static void fill_geometry(int dtype, LdsGeometry* g)
     g->slots = g->block / g->tx;
     g->npass = SC::RD::npass;
     for (int i = 0; i < 4; ++i) g->radix[i] = SC::RD::r[i];
+    g->split16 = SC::RD::split16 ? 1 : 0;
     g->lds_bytes = (SC::RD::npass > 1)
                        ? (dtype == MFFT_C64 ? lds_bytes_for<float, L>() : lds_bytes_for<double, L>())
                        : 0;

@@ -60,13 +60,18 @@ void build_lds_twiddles(const LdsGeometry& g, std::vector<long double>* re, std:
     for (int s = 0; s < g.npass; ++s) {
         const int r = g.radix[s];
         if (s > 0) {
-            for (int i = 1; i < r; ++i)
+            // powers stored per pass: all of 1..r-1, or the six generators of a radix-16 pass
+            static const int split16[6] = {1, 2, 3, 4, 8, 12};
+            const int rows = tw_rows(r, g.split16 != 0);
+            for (int row = 0; row < rows; ++row) {
+                const int i = (rows == r - 1) ? row + 1 : split16[row];
                 for (int m = 0; m < ns; ++m) {
                     long double c, d;
                     unit_root((int64_t)m * i, (int64_t)ns * r, &c, &d);
                     re->push_back(c);
                     im->push_back(d);
                 }
+            }
         }
         ns *= r;
     }
