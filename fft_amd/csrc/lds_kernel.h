@@ -249,8 +249,7 @@ template <class RD> constexpr int tw_total_elems()
 // bytes the shared tables need behind the data slots.
 template <class RD, int TX, int P, int VAR> constexpr int tw_source()
 {
-    constexpr bool general = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
-    if (general || RD::npass < 2) return TW_GLOBAL;
+    if (RD::npass < 2) return TW_GLOBAL;
     if (MFFT_TW_SRC == TW_REG) return twreg_count<RD, TX, P>() <= (RD::split16 ? 12 : 18) ? TW_REG : TW_GLOBAL;
     if (MFFT_TW_SRC == TW_LDS) return tw_total_elems<RD>() <= 2048 ? TW_LDS : TW_GLOBAL;
     return TW_GLOBAL;
@@ -334,19 +333,49 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                 }
             }
         } else {
+            // Runtime prologue.  Every load is issued unconditionally at a clamped index and the
+            // options are uniform branches around whole 16-load loops, so the loads of one signal
+            // stay in flight together (a per-element branch would serialise them).
+            const int64_t bl = active ? b : a.batch - 1;
+            const int64_t base = bl * a.in_stride;
+            const int last = a.n_in - 1;
+            int jj[P];
 #pragma unroll
-            for (int e = 0; e < P; ++e) {
-                const int j = t + TX * e;
-                C x{0, 0};
-                if (active && j < a.n_in) {
-                    const int64_t at = b * a.in_stride + seg_index(j, a.in_seg, a.in_seg_stride);
-                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[at];
-                    else x = reinterpret_cast<const C*>(a.in)[at];
-                    if (a.conj_in) x.y = -x.y;
-                    if (a.win) { const T w = a.win[j]; x.x *= w; x.y *= w; }
-                    if (a.pre) x = cmul(x, a.pre[j]);
+            for (int e = 0; e < P; ++e) { const int j = t + TX * e; jj[e] = j < last ? j : last; }
+            int64_t at[P];
+            if (a.in_seg > 0) {
+                const uint32_t seg = (uint32_t)a.in_seg;
+#pragma unroll
+                for (int e = 0; e < P; ++e)
+                    at[e] = base + (int64_t)((uint32_t)jj[e] / seg) * a.in_seg_stride + (int64_t)((uint32_t)jj[e] % seg);
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) at[e] = base + jj[e];
+            }
+            if (a.real_in) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = C{reinterpret_cast<const T*>(a.in)[at[e]], 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = reinterpret_cast<const C*>(a.in)[at[e]];
+            }
+            if (a.conj_in) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
+            }
+            if (a.win) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { const T w = a.win[jj[e]]; v[e].x *= w; v[e].y *= w; }
+            }
+            if (a.pre) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.pre[jj[e]]);
+            }
+            if (a.n_in < N) {          // zero padding: samples beyond n_in
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    if (t + TX * e > last) v[e] = C{0, 0};
                 }
-                v[e] = x;
             }
         }
 
@@ -371,24 +400,38 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
         if constexpr (POWER) {
             T* __restrict__ dst = reinterpret_cast<T*>(a.out) + b * a.out_stride;
             T s[P];
+            if constexpr (GENERAL) {
+                if (a.post) {                  // |.|^2 ignores conj_out
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
+                        const int k = t + TX * e;
+                        v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < P; ++e) {
-                C o{v[e].x * a.scale, v[e].y * a.scale};
-                if constexpr (GENERAL) {
-                    const int k = t + TX * e;
-                    if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);   // |.|^2 ignores conj_out
-                }
-                s[e] = o.x * o.x + o.y * o.y;
+                const T re = v[e].x * a.scale, im = v[e].y * a.scale;
+                s[e] = re * re + im * im;
             }
             if (active) {
+                if constexpr (GENERAL) {
+                    if (a.out_seg > 0) {
+                        const uint32_t seg = (uint32_t)a.out_seg;
 #pragma unroll
-                for (int e = 0; e < P; ++e) {
-                    if constexpr (GENERAL) {
-                        const int k = t + TX * e;
-                        if (k < a.n_out) dst[seg_index(k, a.out_seg, a.out_seg_stride)] = s[e];
+                        for (int e = 0; e < P; ++e) {
+                            const uint32_t k = (uint32_t)(t + TX * e);
+                            if ((int)k < a.n_out) dst[(int64_t)(k / seg) * a.out_seg_stride + (k % seg)] = s[e];
+                        }
                     } else {
-                        st_stream(dst + t + TX * e, s[e]);
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            if (t + TX * e < a.n_out) dst[t + TX * e] = s[e];
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, s[e]);
                 }
             }
             if constexpr (VAR == V_GEN_POWER) {
@@ -422,18 +465,39 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
             }
         } else {
             C* __restrict__ dst = reinterpret_cast<C*>(a.out) + b * a.out_stride;
-            if (active) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) {
-                    C o{v[e].x * a.scale, v[e].y * a.scale};
-                    if constexpr (GENERAL) {
+            for (int e = 0; e < P; ++e) { v[e].x *= a.scale; v[e].y *= a.scale; }
+            if constexpr (GENERAL) {
+                if (a.conj_out) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
+                }
+                if (a.post) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
                         const int k = t + TX * e;
-                        if (a.conj_out) o.y = -o.y;
-                        if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
-                        if (k < a.n_out) dst[seg_index(k, a.out_seg, a.out_seg_stride)] = o;
-                    } else {
-                        st_stream(dst + t + TX * e, o);
+                        v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
                     }
+                }
+            }
+            if (active) {
+                if constexpr (GENERAL) {
+                    if (a.out_seg > 0) {
+                        const uint32_t seg = (uint32_t)a.out_seg;
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            const uint32_t k = (uint32_t)(t + TX * e);
+                            if ((int)k < a.n_out) dst[(int64_t)(k / seg) * a.out_seg_stride + (k % seg)] = v[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            if (t + TX * e < a.n_out) dst[t + TX * e] = v[e];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, v[e]);
                 }
             }
         }

@@ -140,19 +140,48 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
 #pragma unroll
             for (int e = 0; e < P; ++e) { v[e] = *p; p += pstep; }
         } else if constexpr (MODE == TM_FIRST_GEN) {
+            // runtime prologue: unconditional loads at clamped indices, options as uniform
+            // branches around whole loops (keeps the tile's loads in flight together)
+            const int64_t last = a.n_in - 1;
+            int64_t idx[P];
 #pragma unroll
             for (int e = 0; e < P; ++e) {
-                const int64_t idx = j + (int64_t)(t + TX * e) * a.L;   // sample index in the signal
-                C_ x{0, 0};
-                if (idx < a.n_in) {
-                    const int64_t at = b * a.in_stride + seg_index(idx, a.in_seg, a.in_seg_stride);
-                    if (a.real_in) x.x = reinterpret_cast<const T*>(a.in)[at];
-                    else x = reinterpret_cast<const C_*>(a.in)[at];
-                    if (a.conj_in) x.y = -x.y;
-                    if (a.win) { const T wv = a.win[idx]; x.x *= wv; x.y *= wv; }
-                    if (a.pre) x = cmul(x, a.pre[idx]);
+                const int64_t i = j + (int64_t)(t + TX * e) * a.L;   // sample index in the signal
+                idx[e] = i < last ? i : last;
+            }
+            const int64_t base = b * a.in_stride;
+            if (a.in_seg > 0) {
+                if (a.real_in) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e)
+                        v[e] = C_{reinterpret_cast<const T*>(a.in)[base + seg_index(idx[e], a.in_seg, a.in_seg_stride)], 0};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e)
+                        v[e] = reinterpret_cast<const C_*>(a.in)[base + seg_index(idx[e], a.in_seg, a.in_seg_stride)];
                 }
-                v[e] = x;
+            } else if (a.real_in) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = C_{reinterpret_cast<const T*>(a.in)[base + idx[e]], 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = reinterpret_cast<const C_*>(a.in)[base + idx[e]];
+            }
+            if (a.conj_in) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
+            }
+            if (a.win) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { const T wv = a.win[idx[e]]; v[e].x *= wv; v[e].y *= wv; }
+            }
+            if (a.pre) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.pre[idx[e]]);
+            }
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                if (j + (int64_t)(t + TX * e) * a.L > last) v[e] = C_{0, 0};   // zero padding
             }
         } else {
             const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
@@ -226,24 +255,38 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             for (int e = 0; e < P; ++e) { *q = v[e]; q += qstep; }
         } else {
             double mx = 0.0, sm = 0.0, sk = 0.0;
+            int64_t kk[P];
 #pragma unroll
-            for (int e = 0; e < P; ++e) {
-                const int64_t k = j + (int64_t)(t + TX * e) * a.NS;
-                C_ o{v[e].x * a.scale, v[e].y * a.scale};
-                if (a.conj_out) o.y = -o.y;
-                if (a.post) o = cmul(o, a.post[k < a.n_out ? k : 0]);
-                if constexpr (MODE == TM_LAST_POWER) {
-                    const T s = o.x * o.x + o.y * o.y;
+            for (int e = 0; e < P; ++e) kk[e] = j + (int64_t)(t + TX * e) * a.NS;
+#pragma unroll
+            for (int e = 0; e < P; ++e) { v[e].x *= a.scale; v[e].y *= a.scale; }
+            if (a.conj_out) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
+            }
+            if (a.post) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.post[kk[e] < a.n_out ? kk[e] : a.n_out - 1]);
+            }
+            const int64_t obase = b * a.out_stride;
+            if constexpr (MODE == TM_LAST_POWER) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    const T s = v[e].x * v[e].x + v[e].y * v[e].y;
+                    const int64_t k = kk[e];
                     if (k < a.n_out) {
-                        reinterpret_cast<T*>(a.out)[b * a.out_stride + seg_index(k, a.out_seg, a.out_seg_stride)] = s;
+                        reinterpret_cast<T*>(a.out)[obase + seg_index(k, a.out_seg, a.out_seg_stride)] = s;
                         const double f = (k < (a.n_out + 1) / 2) ? (double)k : (double)(k - a.n_out);
                         mx = (double)s > mx ? (double)s : mx;
                         sm += (double)s;
                         sk += f * (double)s;
                     }
-                } else {
-                    if (k < a.n_out)
-                        reinterpret_cast<C_*>(a.out)[b * a.out_stride + seg_index(k, a.out_seg, a.out_seg_stride)] = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    if (kk[e] < a.n_out)
+                        reinterpret_cast<C_*>(a.out)[obase + seg_index(kk[e], a.out_seg, a.out_seg_stride)] = v[e];
                 }
             }
             if constexpr (MODE == TM_LAST_POWER) {
