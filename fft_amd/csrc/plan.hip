@@ -185,6 +185,37 @@ __global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_
     }
 }
 
+// f[j] = sum_k vrow[k] * (exp(-i w[k] t_j / hbar) * c0[k]); the small per-block constants
+// travel in the kernel argument buffer
+struct AmpArgs {
+    int nk;
+    double hbar;
+    double w[32];
+    double c0[64];
+    double vrow[64];
+};
+
+__global__ void return_amplitude_kernel(cx<double>* out, int64_t n, const double* times, double t0, double dt,
+                                        const AmpArgs a)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const double t = times ? times[j] : t0 + (double)j * dt;
+        double fr = 0.0, fi = 0.0;
+        for (int k = 0; k < a.nk; ++k) {
+            double sn, cs;
+            sincos((a.w[k] * t) / a.hbar, &sn, &cs);
+            // tmp = exp(-i phi) * c0[k]
+            const double cr = a.c0[2 * k], ci = a.c0[2 * k + 1];
+            const double tr = cs * cr + sn * ci, ti = cs * ci - sn * cr;
+            // f += vrow[k] * tmp
+            const double vr = a.vrow[2 * k], vi = a.vrow[2 * k + 1];
+            fr += vr * tr - vi * ti;
+            fi += vr * ti + vi * tr;
+        }
+        out[j] = cx<double>{fr, fi};
+    }
+}
+
 // out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and
 // epilogue of the general path applied to sample 0.
 template <typename T>
@@ -831,6 +862,64 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     if (h_out) MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
     if (p->flags & MFFT_STATS)
         MFFT_HIP(hipMemcpy(h_stats, p->d_stats, sizeof(double) * 3 * (size_t)p->batch, hipMemcpyDeviceToHost));
+    return MFFT_OK;
+}
+
+static int amp_args(AmpArgs* a, const double* w, const double* c0, const double* vrow, int nk, double hbar)
+{
+    if (!w || !c0 || !vrow || nk < 1 || nk > 32 || hbar == 0.0) { set_error("bad block description (1 <= nk <= 32)"); return MFFT_E_INVALID; }
+    a->nk = nk;
+    a->hbar = hbar;
+    memcpy(a->w, w, sizeof(double) * (size_t)nk);
+    memcpy(a->c0, c0, sizeof(double) * 2 * (size_t)nk);
+    memcpy(a->vrow, vrow, sizeof(double) * 2 * (size_t)nk);
+    return MFFT_OK;
+}
+
+int mfft_return_amplitude(void* d_out, int64_t n, double t0, double dt, const double* h_w, const double* h_c0,
+                          const double* h_vrow, int nk, double hbar, void* stream)
+{
+    if (!d_out || n < 0) { set_error("bad argument"); return MFFT_E_INVALID; }
+    AmpArgs a;
+    const int rc = amp_args(&a, h_w, h_c0, h_vrow, nk, hbar);
+    if (rc) return rc;
+    if (n == 0) return MFFT_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(return_amplitude_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<cx<double>*>(d_out), n, (const double*)nullptr, t0, dt, a);
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_return_amplitude_host(void* h_out, int64_t n, const double* h_times, double t0, double dt,
+                               const double* h_w, const double* h_c0, const double* h_vrow, int nk, double hbar)
+{
+    if (!h_out || n < 0) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
+    AmpArgs a;
+    int rc = amp_args(&a, h_w, h_c0, h_vrow, nk, hbar);
+    if (rc) return rc;
+    if (n == 0) return MFFT_OK;
+    void* d_out = nullptr;
+    double* d_t = nullptr;
+    MFFT_HIP(hipMalloc(&d_out, (size_t)n * sizeof(cx<double>)));
+    hipError_t e = hipSuccess;
+    if (h_times) {
+        e = hipMalloc((void**)&d_t, (size_t)n * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(d_t, h_times, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(return_amplitude_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr,
+                           static_cast<cx<double>*>(d_out), n, (const double*)d_t, t0, dt, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, (size_t)n * sizeof(cx<double>), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (d_t) (void)hipFree(d_t);
+    if (e != hipSuccess) return hip_fail(e, "return_amplitude", __FILE__, __LINE__);
     return MFFT_OK;
 }
 

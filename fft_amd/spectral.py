@@ -166,19 +166,59 @@ def fft_from_timeseries(
 
 # --------------------------------------------------------------------------- estimator B
 
-def return_amplitude(Htop, site, times, hbar=1.0):
-    """f(t) = <site| exp(-i H t / hbar) |site> on the time grid, from the
-    eigendecomposition of the (small, Hermitian) block H
-    (streamlit_app_combined.py:86-93, :166-169)."""
-    H = np.asarray(Htop)
+def _amplitude_on_device(H, site, times, hbar=1.0):
+    """f(t_j) = <site| exp(-i H t_j / hbar) |site> for every t_j, evaluated on the GPU.
+
+    The eigendecomposition of the small Hermitian block stays on the host (L <= 10 in
+    the apps); the per-time work -- the Python loop of evolve_state_in_H
+    (final2.py:85-91, streamlit_app_combined.py:86-93), the apps' own hot loop -- runs
+    as one kernel: f_j = V[site, :] . (exp(-i w t_j / hbar) * c0),  c0 = V^H |site>."""
+    import ctypes
+    H = np.asarray(H)
+    if H.ndim != 2 or H.shape[0] != H.shape[1]:
+        raise ValueError("H must be a square matrix")
+    if H.shape[0] > 32:
+        raise ValueError("blocks larger than 32 x 32 are not supported by the device generator")
     w, V = np.linalg.eigh(H)
-    c0 = V[site, :].conj()                        # V^H |site>
-    # Same operation order as evolving the ket and reading its `site` component:
-    # V[site, :] . (exp(-i w t / hbar) * c0).  For an exactly symmetric spectrum f(t) is real
-    # up to rounding, and the +E / -E sign search downstream is decided by that rounding,
-    # so the order of these operations is part of the reference's observable behaviour.
-    phases = np.exp(-1j * np.outer(np.asarray(times, float), w.real) / hbar)
-    return (phases * c0[None, :]) @ V[site, :]
+    w = np.ascontiguousarray(w.real, dtype=np.float64)
+    psi0 = np.zeros(H.shape[0], complex)
+    psi0[site] = 1.0
+    c0 = np.ascontiguousarray(V.conj().T @ psi0, dtype=np.complex128)
+    vrow = np.ascontiguousarray(V[site, :], dtype=np.complex128)
+    t = np.ascontiguousarray(times, dtype=np.float64)
+    out = np.empty(t.shape[0], dtype=np.complex128)
+    lib = _lib.load()
+    _lib.check(lib.mfft_return_amplitude_host(
+        out.ctypes.data, t.shape[0], t.ctypes.data, 0.0, 0.0, w.ctypes.data, c0.ctypes.data,
+        vrow.ctypes.data, int(H.shape[0]), float(hbar)))
+    return out
+
+
+def return_amplitude(Htop, site, times, hbar=1.0):
+    """Drop-in for streamlit_app_combined.py:166-169 (return amplitude of the 3 x 3 top block)."""
+    return _amplitude_on_device(Htop, site, times, hbar)
+
+
+def Heff_block_general(K, J, m):
+    """L x L effective block for one top excitation with the bottom one fixed at m
+    (final2.py:47-64): diagonal S at i == m, S - 2(K[i] + K[m]) elsewhere, S = sum(K);
+    J on the first off-diagonals."""
+    K = np.asarray(K, float)
+    J = np.asarray(J, float)
+    L = len(K)
+    S = float(np.sum(K))
+    d = S - 2.0 * (K + K[m])
+    d[m] = S
+    H = np.diag(d)
+    i = np.arange(L - 1)
+    H[i, i + 1] = J
+    H[i + 1, i] = J
+    return H
+
+
+def return_amplitude_block_general(K, J, bottom_m, site, times, hbar=1.0):
+    """Drop-in for final2.py:93-97: f(t) of block `bottom_m` at top site `site`."""
+    return _amplitude_on_device(Heff_block_general(K, J, bottom_m), site, times, hbar)
 
 
 def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=True):

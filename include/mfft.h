@@ -113,6 +113,21 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale,
                    double mu, double t0, double dt, double* h_stats);
 
+/* ---- input generator -----------------------------------------------------------
+ * Return amplitude of a small Hermitian block on a time grid,
+ *     f[j] = sum_k vrow[k] * ( exp(-i * w[k] * t_j / hbar) * c0[k] ),   k < nk <= 32
+ * which is what evolve_state_in_H + kets[:, site] compute one time step at a time in a
+ * Python loop (final2.py:85-97; streamlit_app_combined.py:86-93, :166-169): w are the
+ * eigenvalues, c0 = V^H psi0 and vrow = V[site, :].  t_j = h_times[j] when h_times is not
+ * NULL, else t0 + j*dt.  h_* are host arrays (c0, vrow: interleaved re, im doubles); h_out
+ * receives n complex128 values.  Evaluated in double precision on the device. */
+int mfft_return_amplitude_host(void* h_out, int64_t n, const double* h_times, double t0, double dt,
+                               const double* h_w, const double* h_c0, const double* h_vrow, int nk,
+                               double hbar);
+/* Same, writing n complex128 values to device memory (uniform grid only), asynchronous. */
+int mfft_return_amplitude(void* d_out, int64_t n, double t0, double dt, const double* h_w,
+                          const double* h_c0, const double* h_vrow, int nk, double hbar, void* stream);
+
 /* ---- element-wise helpers used around the transform ------------------------ */
 
 /* out[k] = in[k] / (m > 0 ? m : 1) with m = *d_max  -- S / (S.max() if S.max() > 0 else 1.0), final2.py:146.

@@ -106,13 +106,11 @@ def test_refine_and_fit_match_oracle():
     assert np.linalg.norm(basis @ coef - xw) < 1e-12
 
 
-def test_return_amplitude_matches_oracle(golden):
+def test_heff_block_matches_oracle():
     import fft_amd
-    z = golden("combined_defaults.npz")
-    times = np.arange(0.0, 15.0 + 0.01, 0.01)
-    f = fft_amd.return_amplitude(z["Htop"], 2, times)
-    assert rel_l2(f, z["f_t"]) < 1e-13
-    assert rel_l2(f, so.return_amplitude_top(z["Htop"], 2, times)) < 1e-13
+    K, J = [1.0, 0.7, 1.3, 0.2], [0.5, 1.5, 0.9]
+    for m in range(4):
+        assert np.array_equal(fft_amd.Heff_block_general(K, J, m), so.heff_block(K, J, m))
 
 
 def test_engine_dtype_promotion():
