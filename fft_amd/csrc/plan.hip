@@ -791,6 +791,11 @@ int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, 
     p->n = n; p->n_in = n_in; p->batch = batch; p->dtype = dtype; p->flags = flags;
     if (in_layout) p->lin = *in_layout;
     if (out_layout) p->lout = *out_layout;
+    // a segment at least as long as the signal is no segmentation: keep the fast kernels
+    if (p->lin.seg >= n_in) p->lin.seg = p->lin.seg_stride = 0;
+    if (p->lout.seg >= n) p->lout.seg = p->lout.seg_stride = 0;
+    if (p->lin.batch_stride == n_in && p->lin.seg == 0) p->lin.batch_stride = 0;
+    if (p->lout.batch_stride == n && p->lout.seg == 0) p->lout.batch_stride = 0;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("hipGetDevice failed"); return MFFT_E_HIP; }
     const int rc = plan_build(p);
     if (rc != MFFT_OK) { plan_free(p); return rc; }

@@ -43,7 +43,7 @@ def shard_range(total: int, world: int, rank: int):
 # --------------------------------------------------------------------------- communication
 
 class Comm:
-    """The exchange step.  world == 1 degenerates to a copy."""
+    """The exchange step.  With a single rank it degenerates to handing the buffer back."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -57,11 +57,12 @@ class Comm:
             self.world, self.rank, self.backend = 1, 0, "none"
 
     def all_to_all(self, dst, src):
-        """dst[r-th equal chunk] <- rank r's src[my chunk]; complex tensors, 1-D, equal splits."""
+        """Exchange equal chunks: the r-th chunk of the result is rank r's src[my chunk].
+        Returns the tensor that holds the result -- `dst`, or `src` itself when there is only
+        one rank (no copy); the other one is free for reuse by the caller."""
         import torch
         if self.world == 1:
-            dst.copy_(src)
-            return
+            return src
         d, s = torch.view_as_real(dst), torch.view_as_real(src)
         if self.backend == "gloo" and src.is_cuda:
             # rehearsal mode (several ranks sharing one GPU box): stage through the host
@@ -71,6 +72,7 @@ class Comm:
             d.copy_(dc)
         else:
             self._dist.all_to_all_single(d, s, group=self.group)
+        return dst
 
 
 # --------------------------------------------------------------------------- local operations
@@ -144,20 +146,27 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
     R, W = n0 // P, n1 // P
     if a_local.numel() != R * n1:
         raise ValueError("a_local has the wrong size for this rank's slab")
-    buf_a = ops.empty(R * n1, a_local)
-    buf_b = ops.empty(R * n1, a_local)
+    x = ops.empty(R * n1, a_local)
+    y = ops.empty(R * n1, a_local)
+
+    def other(t):
+        return y if t is x else x
+
     # row FFTs; bin k of local row i is stored at [k // W][i][k % W]: already packed per destination
-    ops.fft(a_local, buf_a, n=n1, batch=R, out_layout=(W, W, R * W))
-    comm.all_to_all(buf_b, buf_a)                  # buf_b[r][i][c]: an (n0 x W) matrix [global row][local col]
-    ops.transpose(buf_b, buf_a, rows=n0, cols=W)   # -> (W x n0): each local column contiguous
+    ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
+    cur = comm.all_to_all(y, x)                    # cur[r][i][c]: an (n0 x W) matrix [global row][local col]
+    nxt = other(cur)
+    ops.transpose(cur, nxt, rows=n0, cols=W)       # -> (W x n0): each local column contiguous
+    cur, nxt = nxt, cur
     if not restore_layout:
-        ops.fft(buf_a, buf_b, n=n0, batch=W)
-        return buf_b
+        ops.fft(cur, nxt, n=n0, batch=W)
+        return nxt
     # column FFTs; bin k0 of local column c goes to [k0 // R][c][k0 % R], packed for the way back
-    ops.fft(buf_a, buf_b, n=n0, batch=W, out_layout=(R, R, W * R))
-    comm.all_to_all(buf_a, buf_b)                  # buf_a[s][c][i]: an (n1 x R) matrix [global col][local row]
-    ops.transpose(buf_a, buf_b, rows=n1, cols=R)   # -> (R x n1)
-    return buf_b
+    ops.fft(cur, nxt, n=n0, batch=W, out_layout=(R, R, W * R))
+    cur = comm.all_to_all(cur, nxt)                # cur[s][c][i]: an (n1 x R) matrix [global col][local row]
+    nxt = other(cur)
+    ops.transpose(cur, nxt, rows=n1, cols=R)       # -> (R x n1)
+    return nxt
 
 
 # --------------------------------------------------------------------------- large 1-D four-step
@@ -182,23 +191,31 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
     R1, W2 = n1 // P, n2 // P
     if x_local.numel() != R1 * n2:
         raise ValueError("x_local has the wrong size for this rank's chunk")
-    buf_a = ops.empty(R1 * n2, x_local)
-    buf_b = ops.empty(R1 * n2, x_local)
+    x = ops.empty(R1 * n2, x_local)
+    y = ops.empty(R1 * n2, x_local)
+
+    def other(t):
+        return y if t is x else x
+
     # local rows j1 (R1 x n2) -> (n2 x R1): destination s owns rows [s*W2, (s+1)*W2), contiguous
-    ops.transpose(x_local, buf_a, rows=R1, cols=n2)
-    comm.all_to_all(buf_b, buf_a)                  # buf_b[r][c][i] = x[(r*R1 + i)*n2 + rank*W2 + c]
+    ops.transpose(x_local, x, rows=R1, cols=n2)
+    cur = comm.all_to_all(y, x)                    # cur[r][c][i] = x[(r*R1 + i)*n2 + rank*W2 + c]
+    nxt = other(cur)
     # n1-point FFT over j1 for each local column c.  Sample j1 sits at [j1 // R1][c][j1 % R1];
     # bin k1 is stored at [k1 // R1][c][k1 % R1], i.e. packed for the owner of that k1 block.
     seg = (R1, R1, W2 * R1)
-    ops.fft(buf_b, buf_a, n=n1, batch=W2, in_layout=seg, out_layout=seg)
-    comm.all_to_all(buf_b, buf_a)                  # buf_b[s][c][i] = A[j2 = s*W2 + c][k1 = rank*R1 + i]: (n2 x R1)
-    ops.twiddle(buf_b, rows=n2, cols=R1, r0=0, c0=comm.rank * R1, n_total=n)
-    ops.transpose(buf_b, buf_a, rows=n2, cols=R1)  # -> (R1 x n2): each local k1 row contiguous in j2
+    ops.fft(cur, nxt, n=n1, batch=W2, in_layout=seg, out_layout=seg)
+    cur = comm.all_to_all(cur, nxt)                # cur[s][c][i] = A[j2 = s*W2 + c][k1 = rank*R1 + i]: (n2 x R1)
+    nxt = other(cur)
+    ops.twiddle(cur, rows=n2, cols=R1, r0=0, c0=comm.rank * R1, n_total=n)
+    ops.transpose(cur, nxt, rows=n2, cols=R1)      # -> (R1 x n2): each local k1 row contiguous in j2
+    cur, nxt = nxt, cur
     if not natural_order:
-        ops.fft(buf_a, buf_b, n=n2, batch=R1)
-        return buf_b
+        ops.fft(cur, nxt, n=n2, batch=R1)
+        return nxt
     # n2-point FFT over j2; bin k2 of local row i goes to [k2 // W2][i][k2 % W2] (owner of natural index k2*n1 + k1)
-    ops.fft(buf_a, buf_b, n=n2, batch=R1, out_layout=(W2, W2, R1 * W2))
-    comm.all_to_all(buf_a, buf_b)                  # buf_a[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
-    ops.transpose(buf_a, buf_b, rows=n1, cols=W2)  # -> (W2 x n1) = natural-order chunk
-    return buf_b
+    ops.fft(cur, nxt, n=n2, batch=R1, out_layout=(W2, W2, R1 * W2))
+    cur = comm.all_to_all(cur, nxt)                # cur[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
+    nxt = other(cur)
+    ops.transpose(cur, nxt, rows=n1, cols=W2)      # -> (W2 x n1) = natural-order chunk
+    return nxt
