@@ -216,6 +216,21 @@ __global__ void return_amplitude_kernel(cx<double>* out, int64_t n, const double
     }
 }
 
+// indices of interior local maxima (left strict, right weak), unordered, with a total count
+template <typename T>
+__global__ void local_maxima_kernel(const T* S, int64_t n, int64_t* idx, int64_t capacity,
+                                    unsigned long long* count)
+{
+    for (int64_t i = 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n - 1;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T c = S[i];
+        if (c > S[i - 1] && c >= S[i + 1]) {
+            const unsigned long long slot = atomicAdd(count, 1ULL);
+            if ((int64_t)slot < capacity) idx[slot] = i;
+        }
+    }
+}
+
 // out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and
 // epilogue of the general path applied to sample 0.
 template <typename T>
@@ -509,6 +524,8 @@ struct Plan {
     void* d_in = nullptr;
     void* d_out = nullptr;
     double* d_stats = nullptr;
+    int64_t* d_peaks = nullptr;   // [0] = count, [1..] = candidate indices (mfft_exec_host_peaks)
+    int64_t peak_cap = 0;
     int64_t workspace = 0;
     int launches = 1;
     std::mutex mu;
@@ -533,7 +550,8 @@ static void plan_free(Plan* p)
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     (void)hipSetDevice(p->device);
     p->eng.release();
-    for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats})
+    for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
+                    (void*)p->d_peaks})
         if (q) (void)hipFree(q);
     if (have_prev) (void)hipSetDevice(prev);
     delete p;
@@ -925,6 +943,55 @@ int mfft_return_amplitude_host(void* h_out, int64_t n, const double* h_times, do
     (void)hipFree(d_out);
     if (d_t) (void)hipFree(d_t);
     if (e != hipSuccess) return hip_fail(e, "return_amplitude", __FILE__, __LINE__);
+    return MFFT_OK;
+}
+
+int mfft_local_maxima(const void* d_S, int64_t n, int dtype, int64_t* d_idx, int64_t capacity,
+                      int64_t* d_count, void* stream)
+{
+    if ((!d_S && n >= 3) || (!d_idx && capacity > 0) || !d_count || n < 0 || capacity < 0) {
+        set_error("bad argument"); return MFFT_E_INVALID;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MFFT_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+    if (n < 3) return MFFT_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == MFFT_C64)
+        hipLaunchKernelGGL(local_maxima_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const float*>(d_S), n, d_idx, capacity,
+                           reinterpret_cast<unsigned long long*>(d_count));
+    else if (dtype == MFFT_C128)
+        hipLaunchKernelGGL(local_maxima_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const double*>(d_S), n, d_idx, capacity,
+                           reinterpret_cast<unsigned long long*>(d_count));
+    else { set_error("bad dtype"); return MFFT_E_INVALID; }
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu, double t0,
+                         double dt, double* h_stats, int64_t* h_idx, int64_t capacity, int64_t* h_count)
+{
+    if (!plan || !h_in || !h_out || !h_idx || !h_count || capacity < 1) { set_error("null argument"); return MFFT_E_INVALID; }
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    if (!(p->flags & MFFT_POWER) || p->batch != 1) { set_error("peak scan needs a one-signal MFFT_POWER plan"); return MFFT_E_INVALID; }
+    int rc = mfft_exec_host(plan, h_in, h_out, scale, mu, t0, dt, h_stats);
+    if (rc) return rc;
+    DeviceGuard g(p->device);
+    if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (p->peak_cap < capacity) {
+        if (p->d_peaks) (void)hipFree(p->d_peaks);
+        p->d_peaks = nullptr;
+        MFFT_HIP(hipMalloc((void**)&p->d_peaks, sizeof(int64_t) * (size_t)(capacity + 1)));
+        p->peak_cap = capacity;
+    }
+    rc = mfft_local_maxima(p->d_out, p->n, p->dtype, p->d_peaks + 1, capacity, p->d_peaks, nullptr);
+    if (rc) return rc;
+    MFFT_HIP(hipMemcpy(h_count, p->d_peaks, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t take = *h_count < capacity ? *h_count : capacity;
+    if (take > 0) MFFT_HIP(hipMemcpy(h_idx, p->d_peaks + 1, sizeof(int64_t) * (size_t)take, hipMemcpyDeviceToHost));
     return MFFT_OK;
 }
 

@@ -108,6 +108,30 @@ class Plan:
             return stats
         return (out, stats) if stats is not None else out
 
+    def exec_host_peaks(self, x: np.ndarray, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0,
+                        dt: float = 1.0, capacity: int = 65536):
+        """exec_host for a one-signal POWER|STATS plan plus the device-side scan for interior
+        local maxima.  Returns (S, stats, idx) with idx ascending, or idx = None when more than
+        `capacity` maxima exist (the caller then scans S itself)."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        if not (self.flags & _lib.POWER and self.flags & _lib.STATS) or self.batch != 1:
+            raise ValueError("exec_host_peaks needs a one-signal POWER|STATS plan")
+        x = np.ascontiguousarray(x, dtype=self.in_dtype)
+        if x.size != self.n_in:
+            raise ValueError(f"input has {x.size} elements, plan expects {self.n_in}")
+        out = np.empty(self.n, dtype=self.out_dtype)
+        stats = np.zeros((1, 3), dtype=np.float64)
+        idx = np.empty(capacity, dtype=np.int64)
+        count = ctypes.c_int64(0)
+        with self._lock:
+            _lib.check(_lib.load().mfft_exec_host_peaks(
+                self._h, x.ctypes.data, out.ctypes.data, float(scale), float(mu), float(t0), float(dt),
+                stats.ctypes.data, idx.ctypes.data, int(capacity), ctypes.byref(count)))
+        if count.value > capacity:
+            return out, stats, None
+        return out, stats, np.sort(idx[:count.value])
+
     # -- lifetime ---------------------------------------------------------------
     def destroy(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -30,12 +30,14 @@ TWO_PI = 2.0 * np.pi
 # --------------------------------------------------------------------------- device part
 
 def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0.0, t0: float = 0.0,
-                   want_spectrum: bool = True):
+                   want_spectrum: bool = True, want_peaks: bool = False):
     """|dt * FFT_nfft(window * x * exp(i mu t))|^2 on the GPU, in double precision.
 
     Returns ``(S, smax, ssum, centroid_bins)`` where ``S`` is float64[nfft] (``None``
     when ``want_spectrum`` is false), ``smax = S.max()``, ``ssum = S.sum()`` and
-    ``centroid_bins = sum(f_k * S)`` with ``f_k`` the signed FFT-order bin index."""
+    ``centroid_bins = sum(f_k * S)`` with ``f_k`` the signed FFT-order bin index.  With
+    ``want_peaks`` a fifth item follows: the ascending indices of the interior local maxima
+    of S (left strict, right weak), found on the device."""
     x = np.asarray(x)
     _, real_in = engine_dtype(x)
     flags = _lib.POWER | _lib.STATS
@@ -47,6 +49,11 @@ def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0
         flags |= _lib.REAL_IN
     plan = cached_plan(nfft, x.shape[0], 1, _lib.C128, flags)
     xin = np.ascontiguousarray(x, dtype=np.float64 if real_in else np.complex128)
+    if want_peaks:
+        S, stats, idx = plan.exec_host_peaks(xin, scale=dt, mu=mu, t0=t0, dt=dt)
+        if idx is None:                       # more maxima than the device buffer holds
+            idx = _local_maxima(S)
+        return S, float(stats[0, 0]), float(stats[0, 1]), float(stats[0, 2]), idx
     if want_spectrum:
         S, stats = plan.exec_host(xin, scale=dt, mu=mu, t0=t0, dt=dt)
     else:
@@ -124,13 +131,12 @@ def fft_from_timeseries(
 
     n0 = len(f_t)
     nfft = int(max(1, pad_factor) * n0)
-    S, smax, _, _ = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann))
+    S, smax, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), want_peaks=True)
     omega = TWO_PI * fftfreq(nfft, d=dt)
     S_norm = S / (smax if smax > 0 else 1.0)
 
     span = times[-1] - times[0]
     domega = TWO_PI / (span + 1e-12)
-    cand = _local_maxima(S)
     if include_dc:
         if S[0] > 0:
             cand = np.unique(np.concatenate(([0], cand)))
@@ -243,11 +249,9 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
     if demod and mu != 0.0:
         xw = xw * np.exp(+1j * mu * times)
 
-    S, _, _, _ = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), mu=mu if demod else 0.0,
-                                t0=float(times[0]))
+    S, _, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), mu=mu if demod else 0.0,
+                                      t0=float(times[0]), want_peaks=True)
     omega = TWO_PI * fftfreq(nfft, d=dt)
-
-    cand = _local_maxima(S)
     if cand.size == 0:
         return np.array([]), np.array([]), omega, S, mu
     by_height = cand[np.argsort(S[cand])][::-1]

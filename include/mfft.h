@@ -113,6 +113,26 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale,
                    double mu, double t0, double dt, double* h_stats);
 
+/* ---- peak candidates ------------------------------------------------------------
+ * Interior local maxima of a real spectrum S[0..n): every i in [1, n-2] with
+ *     S[i-1] < S[i]  and  S[i] >= S[i+1]           (left strict, right weak)
+ * i.e. np.where((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:]))[0] + 1   -- final2.py:151,
+ * streamlit_app_combined.py:218.  Indices are written to d_idx in no particular order
+ * (at most `capacity` of them); *d_count receives the TOTAL number found, which may
+ * exceed capacity (the caller then rescans with a larger buffer).  The call zeroes
+ * *d_count itself, on `stream`.  dtype selects float (MFFT_C64) or double (MFFT_C128)
+ * spectra. */
+int mfft_local_maxima(const void* d_S, int64_t n, int dtype, int64_t* d_idx, int64_t capacity,
+                      int64_t* d_count, void* stream);
+
+/* mfft_exec_host for a one-signal MFFT_POWER plan, followed by mfft_local_maxima on the
+ * device copy of the spectrum: h_out receives S (n reals), h_idx up to `capacity` indices
+ * (unordered), *h_count the total found.  Saves the three host passes over S that the
+ * reference's peak scan makes. */
+int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu,
+                         double t0, double dt, double* h_stats, int64_t* h_idx, int64_t capacity,
+                         int64_t* h_count);
+
 /* ---- input generator -----------------------------------------------------------
  * Return amplitude of a small Hermitian block on a time grid,
  *     f[j] = sum_k vrow[k] * ( exp(-i * w[k] * t_j / hbar) * c0[k] ),   k < nk <= 32

@@ -183,3 +183,38 @@ def test_return_amplitude_generator(fa, golden):
     E, p, _, _ = fa.fft_from_timeseries(fa.return_amplitude_block_general(z["K"], z["J"], 1, 0, times), times, **kw)
     np.testing.assert_allclose(E, z["E_1"], atol=1e-9)
     np.testing.assert_allclose(p, z["p_1"], atol=1e-9)
+
+
+def test_local_maxima_scan(fa):
+    """Device-side candidate scan (final2.py:151, streamlit_app_combined.py:218) against the
+    numpy expression, bit-exact on indices, including plateaus, ties, tiny arrays and overflow."""
+    import ctypes
+    import torch
+    from fft_amd import _lib
+    lib = _lib.load()
+
+    def scan(S, capacity):
+        d_S = torch.from_numpy(S).cuda()
+        d_idx = torch.full((max(capacity, 1),), -1, dtype=torch.int64, device="cuda")
+        d_cnt = torch.full((1,), 77, dtype=torch.int64, device="cuda")
+        _lib.check(lib.mfft_local_maxima(d_S.data_ptr(), S.shape[0], _lib.C64 if S.dtype == np.float32 else _lib.C128,
+                                         d_idx.data_ptr(), capacity, d_cnt.data_ptr(), None))
+        torch.cuda.synchronize()
+        return int(d_cnt.item()), d_idx.cpu().numpy()
+
+    rng = np.random.default_rng(5)
+    for dtype in (np.float32, np.float64):
+        for n in (0, 1, 2, 3, 4, 255, 256, 257, 100003, 1 << 20):
+            # small integers force plateaus and ties: the left-strict / right-weak rule matters
+            S = rng.integers(0, 4, n).astype(dtype)
+            want = np.flatnonzero((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:])) + 1 if n >= 3 else np.zeros(0, int)
+            cnt, idx = scan(S, max(n, 1))
+            assert cnt == want.size, (dtype, n)
+            assert np.array_equal(np.sort(idx[:cnt]), want), (dtype, n)
+    S = rng.random(10000)
+    want = np.flatnonzero((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:])) + 1
+    cnt, idx = scan(S, 100)                               # overflow: total reported, buffer not overrun
+    assert cnt == want.size and cnt > 100
+    assert set(idx[:100].tolist()) <= set(want.tolist())
+    with pytest.raises(ValueError):
+        _lib.check(lib.mfft_local_maxima(None, 8, _lib.C128, None, 8, None, None))
