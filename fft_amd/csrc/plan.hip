@@ -321,6 +321,7 @@ struct Pow2Engine {
     std::vector<GlobalPass> passes;     // tiled decomposition
     void* work[2] = {nullptr, nullptr};
     int64_t bytes = 0;                  // device memory held
+    int tile_nt = 0;                    // TArgs::nt of the plain tile passes
 
     int build(int64_t n_, int64_t batch_, int dtype_);
     void release();
@@ -414,6 +415,11 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
         ns <<= gp.log2g;
     }
     const size_t wbytes = (size_t)n * (size_t)batch * 2 * real_size(dtype);
+    // measured on MI355X (2^15..2^24 points, 128 MiB and 1 GiB per launch): streaming accesses
+    // win 1-15 % on the three-pass lengths (most where the transform fits the Infinity Cache)
+    // and are a wash or a small loss on the two-pass ones
+    tile_nt = passes.size() >= 3 ? 3 : 0;
+    if (const char* env = getenv("MFFT_TILE_NT")) tile_nt = atoi(env) & 3;   // tuning aid
     const int nwork = passes.size() > 2 ? 2 : 1;
     for (int i = 0; i < nwork; ++i) {
         MFFT_HIP(hipMalloc(&work[i], wbytes));
@@ -477,6 +483,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.log2_tiles = log2n - gp.log2g - tile_log2c(dtype, gp.log2g);
         a.batch = batch;
         a.lb = gp.lb;
+        a.nt = tile_nt;
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;

@@ -29,6 +29,32 @@
 
 namespace mfft {
 
+// Plain or non-temporal tile accesses, chosen per pass at run time (uniform branch around the
+// whole load / store loop).  Reads of a pass are dead once consumed while its writes feed the
+// next pass, so when a transform fits the 256 MiB Infinity Cache, streaming the reads past the
+// caches keeps the intermediate resident (2^24 complex64: 179 -> 158 us); for working sets far
+// above the cache, and for two-pass lengths, plain loads measured faster.
+template <typename T, bool NT> __device__ __forceinline__ cx<T> tile_ld(const cx<T>* p)
+{
+    if constexpr (NT) {
+        using V = typename nt_vec<T>::type;
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+        return cx<T>{v.x, v.y};
+    } else {
+        return *p;
+    }
+}
+template <typename T, bool NT> __device__ __forceinline__ void tile_st(cx<T>* p, cx<T> v)
+{
+    if constexpr (NT) {
+        using V = typename nt_vec<T>::type;
+        V w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<V*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 template <typename T> struct TArgs {
     const void* in;
     void* out;
@@ -52,6 +78,7 @@ template <typename T> struct TArgs {
     int log2_ns;          // NS = 1 << log2_ns
     int log2_tiles;       // tiles per signal = (L / C) = 1 << log2_tiles
     int real_in, conj_in, conj_out;
+    int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     T scale;
 };
 
@@ -137,8 +164,13 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
         if constexpr (MODE == TM_FIRST_PLAIN) {
             const C_* __restrict__ p = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j + (int64_t)t * a.L;
             const int64_t pstep = (int64_t)TX * a.L;
+            if (a.nt & 1) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) { v[e] = *p; p += pstep; }
+                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+            }
         } else if constexpr (MODE == TM_FIRST_GEN) {
             // runtime prologue: unconditional loads at clamped indices, options as uniform
             // branches around whole loops (keeps the tile's loads in flight together)
@@ -188,8 +220,13 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             const uint32_t m = (uint32_t)(j & ns_mask);           // NS <= 2^30
             const C_* __restrict__ p = src + (int64_t)t * a.L;
             const int64_t pstep = (int64_t)TX * a.L;
+            if (a.nt & 1) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) { v[e] = *p; p += pstep; }
+                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+            }
 #if !MFFT_DIAG_NOFFT
             const uint32_t lomask = (1u << a.lb) - 1;
             const uint64_t kb = (uint64_t)m * (uint32_t)t;        // base exponent  m*t      < NS*G
@@ -238,21 +275,33 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             for (int e = 0; e < P; ++e) {
                 const int r = threadIdx.x + BLOCK * e;      // element of the run: r = cc*G + q
                 const int cc = r / G, q = r % G;
-                dst[r] = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
+                const C_ val = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
+                if (a.nt & 2) tile_st<T, true>(dst + r, val);
+                else tile_st<T, false>(dst + r, val);
             }
         } else if constexpr (MODE == TM_MID) {
             const int64_t m = j & ns_mask;
             C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride +
                                  ((j >> a.log2_ns) << a.log2_ns) * G + m + (int64_t)t * a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
+            if (a.nt & 2) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) { *q = v[e]; q += qstep; }
+                for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+            }
         } else if constexpr (MODE == TM_LAST_PLAIN) {
             // last pass: NS*G = N, so j < NS and bin k = j + q*NS
             C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j + (int64_t)t * a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
+            if (a.nt & 2) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) { *q = v[e]; q += qstep; }
+                for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+            }
         } else {
             double mx = 0.0, sm = 0.0, sk = 0.0;
             int64_t kk[P];
