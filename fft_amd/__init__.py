@@ -9,13 +9,13 @@ Layers (bottom up):
   dist.py      one-process-per-GPU sharding: batches, 2-D pencils, large 1-D (torch.distributed / RCCL)
 """
 from . import _lib
-from .engine import Plan
+from .engine import Plan, ColumnPlan
 from ._lib import C64, C128, HANN, POWER, DEMOD, REAL_IN, STATS, INVERSE, MfftError, device_count
 from .npfft import fft, fftfreq, clear_plan_cache
 from .spectral import (fft_from_timeseries, fft_extract_E_p, power_spectrum, return_amplitude,
                        return_amplitude_block_general, Heff_block_general)
 
-__all__ = ["Plan", "C64", "C128", "HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE",
+__all__ = ["Plan", "ColumnPlan", "C64", "C128", "HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE",
            "MfftError", "device_count", "fft", "fftfreq", "clear_plan_cache",
            "fft_from_timeseries", "fft_extract_E_p", "power_spectrum", "return_amplitude",
            "return_amplitude_block_general", "Heff_block_general"]

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mfft_plan_1d": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32]),
     "mfft_plan_1d_layout": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32,
                                    ctypes.POINTER(Layout), ctypes.POINTER(Layout)]),
+    "mfft_plan_1d_columns": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _i64, _i64]),
     "mfft_plan_destroy": (_int, [_vp]),
     "mfft_plan_workspace_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
     "mfft_plan_launches": (_int, [_vp, ctypes.POINTER(_int)]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "mfft_return_amplitude": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int, _dbl, _vp]),
     "mfft_normalize_by_max": (_int, [_vp, _vp, _i64, _vp, _int, _vp]),
     "mfft_transpose": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "mfft_swap_axes": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "mfft_twiddle_tile": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
 }
 

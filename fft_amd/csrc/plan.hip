@@ -166,6 +166,30 @@ __global__ void transpose_kernel(const cx<T>* in, cx<T>* out, int64_t rows, int6
     }
 }
 
+// out[b][a][:] = in[a][b][:] for an (A, B, W) array of complex elements: one row of W
+// contiguous elements per loop trip, copied 16 bytes per lane where W allows
+template <typename T>
+__global__ void swap_axes_kernel(const cx<T>* in, cx<T>* out, int64_t A, int64_t B, int64_t W)
+{
+    constexpr int PER16 = 16 / (int)sizeof(cx<T>);            // elements per 16-byte unit
+    const int64_t rows = A * B;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int64_t a = row / B, b = row - a * B;
+        const cx<T>* src = in + row * W;
+        cx<T>* dst = out + (b * A + a) * W;
+        if (W % PER16 == 0) {
+            using V4 = float __attribute__((ext_vector_type(4)));
+            const V4* s4 = reinterpret_cast<const V4*>(src);
+            V4* d4 = reinterpret_cast<V4*>(dst);
+            const int64_t units = W / PER16;
+            for (int64_t u = threadIdx.x; u < units; u += blockDim.x)
+                __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + u), d4 + u);
+        } else {
+            for (int64_t u = threadIdx.x; u < W; u += blockDim.x) dst[u] = src[u];
+        }
+    }
+}
+
 // x[r][c] *= exp(-2*pi*i*(r0+r)*(c0+c)/n): two-level table product, tables built on the host
 template <typename T>
 __global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
@@ -322,8 +346,13 @@ struct Pow2Engine {
     void* work[2] = {nullptr, nullptr};
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
+    int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
+    int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
+    int fs_lb = 0;
+    void* d_fs_lo = nullptr;
+    void* d_fs_hi = nullptr;
 
-    int build(int64_t n_, int64_t batch_, int dtype_);
+    int build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_ = 1, int64_t fs_n_ = 0, int64_t fs_c0_ = 0);
     void release();
     int launches() const { return single ? 1 : (int)passes.size(); }
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
@@ -337,7 +366,7 @@ static int tile_log2c(int dtype, int log2g)
 // How a length above one LDS residency is split into global passes (log2 of each radix, first
 // pass first).  Fewest passes first; within that the radices are balanced, larger ones first.
 // MFFT_SPLIT="8,8,8" overrides the choice (tuning aid; must multiply to the length).
-static int choose_split(int log2n, int dtype, std::vector<int>* out)
+static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_inner = 0)
 {
     out->clear();
     if (const char* env = getenv("MFFT_SPLIT")) {
@@ -349,7 +378,7 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out)
             sum += v;
             if (*p == ',') ++p;
         }
-        if (sum == log2n && out->size() >= 2 && out->size() <= 4) return MFFT_OK;
+        if (sum == log2n && out->size() >= (log2_inner ? 1u : 2u) && out->size() <= 4) return MFFT_OK;
         out->clear();
     }
     const int maxg = kTileMaxLog2G;
@@ -360,20 +389,24 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out)
         const int g = (*out)[s];
         if (g < kTileMinLog2G) { set_error("tile radix too small"); return MFFT_E_UNSUPPORTED; }
         // later passes need NS >= columns per tile; the tile count L/C must be >= 1
-        if (log2n - g < tile_log2c(dtype, g)) { set_error("tile wider than the pass"); return MFFT_E_UNSUPPORTED; }
+        if (log2_inner) {
+            // column-batched: a tile is C adjacent columns of one butterfly
+            if (log2_inner < tile_log2c(dtype, g)) { set_error("fewer columns than a tile is wide"); return MFFT_E_UNSUPPORTED; }
+        } else if (log2n - g < tile_log2c(dtype, g)) { set_error("tile wider than the pass"); return MFFT_E_UNSUPPORTED; }
     }
-    if (out->size() >= 2 && (*out)[0] < tile_log2c(dtype, (*out)[1])) { set_error("first radix below tile width"); return MFFT_E_UNSUPPORTED; }
+    if (!log2_inner && out->size() >= 2 && (*out)[0] < tile_log2c(dtype, (*out)[1])) { set_error("first radix below tile width"); return MFFT_E_UNSUPPORTED; }
     return MFFT_OK;
 }
 
-int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
+int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, int64_t fs_n_, int64_t fs_c0_)
 {
-    n = n_; batch = batch_; dtype = dtype_;
+    n = n_; batch = batch_; dtype = dtype_; inner = inner_; fs_n = fs_n_; fs_c0 = fs_c0_;
     log2n = ilog2(n);
     if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
+    if (!is_pow2(inner)) { set_error("the inner extent of a column-batched transform must be a power of two"); return MFFT_E_UNSUPPORTED; }
     const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
     std::vector<long double> re, im;
-    if (log2n <= maxlog) {
+    if (log2n <= maxlog && inner == 1) {
         single = true;
         if (!lds_geometry(dtype, log2n, &geo)) { set_error("no single-kernel geometry"); return MFFT_E_UNSUPPORTED; }
         build_lds_twiddles(geo, &re, &im);
@@ -382,10 +415,11 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
     }
     single = false;
     std::vector<int> split;
-    int rc0 = choose_split(log2n, dtype, &split);
+    const int log2_inner = ilog2(inner);
+    int rc0 = choose_split(log2n, dtype, &split, log2_inner);
     if (rc0) return rc0;
     const int npass = (int)split.size();
-    int64_t ns = 1;
+    int64_t ns = inner;                 // counts elements: the columns are an innermost, finished "pass"
     for (int s = 0; s < npass; ++s) {
         GlobalPass gp;
         gp.log2g = split[(size_t)s];
@@ -396,8 +430,8 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
         int rc = upload_complex_dt(dtype, re, im, &gp.d_tw);
         if (rc) { passes.push_back(gp); return rc; }
         bytes += (int64_t)re.size() * 2 * (int64_t)real_size(dtype);
-        if (s > 0) {
-            const int64_t m = ns << gp.log2g;
+        if (s > 0 || inner > 1) {
+            const int64_t m = (ns / inner) << gp.log2g;
             const int log2m = ilog2(m);
             gp.lb = log2m < 8 ? log2m : 8;
             const int64_t lo_n = int64_t(1) << gp.lb, hi_n = m >> gp.lb;
@@ -414,13 +448,29 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_)
         passes.push_back(gp);
         ns <<= gp.log2g;
     }
-    const size_t wbytes = (size_t)n * (size_t)batch * 2 * real_size(dtype);
+    if (fs_n > 0 && (!is_pow2(fs_n) || inner == 1)) { set_error("the fused twiddle needs a power-of-two modulus on a column-batched plan"); return MFFT_E_UNSUPPORTED; }
+    if (fs_n > 0) {
+        // two-level table of exp(-2 pi i k / fs_n): k = hi << fs_lb | lo
+        const int bits = ilog2(fs_n);
+        fs_lb = (bits + 1) / 2;
+        const int64_t lo_n = int64_t(1) << fs_lb, hi_n = (fs_n + lo_n - 1) >> fs_lb;
+        re.resize((size_t)lo_n); im.resize((size_t)lo_n);
+        for (int64_t k = 0; k < lo_n; ++k) unit_root(k, fs_n, &re[(size_t)k], &im[(size_t)k]);
+        int rc = upload_complex<double>(re, im, &d_fs_lo);
+        if (rc) return rc;
+        re.resize((size_t)hi_n); im.resize((size_t)hi_n);
+        for (int64_t k = 0; k < hi_n; ++k) unit_root((k << fs_lb) % fs_n, fs_n, &re[(size_t)k], &im[(size_t)k]);
+        rc = upload_complex<double>(re, im, &d_fs_hi);
+        if (rc) return rc;
+        bytes += (lo_n + hi_n) * 2 * (int64_t)sizeof(double);
+    }
+    const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
     // measured on MI355X (2^15..2^24 points, 128 MiB and 1 GiB per launch): streaming accesses
     // win 1-15 % on the three-pass lengths (most where the transform fits the Infinity Cache)
     // and are a wash or a small loss on the two-pass ones
-    tile_nt = passes.size() >= 3 ? 3 : 0;
+    tile_nt = (passes.size() >= 3 || inner > 1) ? 3 : 0;
     if (const char* env = getenv("MFFT_TILE_NT")) tile_nt = atoi(env) & 3;   // tuning aid
-    const int nwork = passes.size() > 2 ? 2 : 1;
+    const int nwork = passes.size() > 2 ? 2 : (passes.size() > 1 ? 1 : 0);
     for (int i = 0; i < nwork; ++i) {
         MFFT_HIP(hipMalloc(&work[i], wbytes));
         bytes += (int64_t)wbytes;
@@ -436,6 +486,9 @@ void Pow2Engine::release()
             if (q) (void)hipFree(q);
     for (void* q : work)
         if (q) (void)hipFree(q);
+    for (void* q : {d_fs_lo, d_fs_hi})
+        if (q) (void)hipFree(q);
+    d_fs_lo = d_fs_hi = nullptr;
     d_tw = nullptr; work[0] = work[1] = nullptr; passes.clear();
 }
 
@@ -466,6 +519,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
     const int np = (int)passes.size();
     const void* src = io.in;
     int64_t src_stride = io.in_stride;
+    const int64_t nn = n * inner;       // elements per transform unit (one signal, or one n x inner array)
+    const int log2nn = log2n + ilog2(inner);
     for (int p = 0; p < np; ++p) {
         const GlobalPass& gp = passes[(size_t)p];
         const bool first = p == 0, last = p == np - 1;
@@ -473,14 +528,15 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.in = src;
         a.in_stride = src_stride;
         a.out = last ? io.out : work[p & 1];
-        a.out_stride = last ? io.out_stride : n;
+        a.out_stride = last ? io.out_stride : nn;
         a.tw = static_cast<const cx<T>*>(gp.d_tw);
         a.tw_lo = static_cast<const cx<double>*>(gp.d_lo);
         a.tw_hi = static_cast<const cx<double>*>(gp.d_hi);
-        a.L = n >> gp.log2g;
+        a.L = nn >> gp.log2g;
         a.NS = gp.ns;
         a.log2_ns = ilog2(gp.ns);
-        a.log2_tiles = log2n - gp.log2g - tile_log2c(dtype, gp.log2g);
+        a.log2_w = ilog2(inner);
+        a.log2_tiles = log2nn - gp.log2g - tile_log2c(dtype, gp.log2g);
         a.batch = batch;
         a.lb = gp.lb;
         a.nt = tile_nt;
@@ -498,14 +554,27 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         const bool in_plain = !io.win && !io.pre && !io.real_in && !io.conj_in && io.n_in == n && io.in_seg == 0;
         const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 &&
                                io.scale == (T)1 && !io.power;
-        const int mode = first ? (in_plain ? TM_FIRST_PLAIN : TM_FIRST_GEN)
-                               : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
+        int mode = first ? (in_plain ? TM_FIRST_PLAIN : TM_FIRST_GEN)
+                         : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
+        if (inner > 1) {
+            // column-batched: every pass is a strided-in / strided-out pass (the first one with
+            // unit twiddles); prologues and epilogues other than the four-step twiddle do not apply
+            if (!in_plain || !out_plain) { set_error("column-batched plans take plain complex data"); return MFFT_E_UNSUPPORTED; }
+            mode = last ? (fs_n > 0 ? TM_LAST_TWID : TM_LAST_PLAIN) : TM_MID;
+            if (last && fs_n > 0) {
+                a.fs_lo = static_cast<const cx<double>*>(d_fs_lo);
+                a.fs_hi = static_cast<const cx<double>*>(d_fs_hi);
+                a.fs_lb = fs_lb;
+                a.fs_mask = (uint64_t)fs_n - 1;
+                a.tw_c0 = fs_c0;
+            }
+        }
         int rc;
         if constexpr (sizeof(T) == 4) rc = launch_tile_c64(gp.log2g, mode, a, s);
         else rc = launch_tile_c128(gp.log2g, mode, a, s);
         if (rc) return rc;
         src = a.out;
-        src_stride = n;
+        src_stride = nn;
     }
     return MFFT_OK;
 }
@@ -518,7 +587,9 @@ struct Plan {
     int dtype = 0;
     uint32_t flags = 0;
     int device = 0;
-    enum Kind { ONE_POINT, POW2, CHIRPZ } kind = POW2;
+    enum Kind { ONE_POINT, POW2, CHIRPZ, COLUMNS } kind = POW2;
+    int64_t inner = 1;       // COLUMNS: contiguous columns sharing each transform, data is (batch, n, inner)
+    int64_t fs_n = 0, fs_c0 = 0;   // COLUMNS: fused four-step twiddle (0 = none)
     mfft_layout lin{0, 0, 0}, lout{0, 0, 0};   // batch_stride 0 = dense default
     Pow2Engine eng;          // length n (POW2) or the padded length m (CHIRPZ)
     int64_t m = 0;           // chirp-z convolution length
@@ -632,6 +703,13 @@ static int plan_build(Plan* p)
         if (rc) return rc;
         p->workspace += p->n_in * (int64_t)real_size(p->dtype);
     }
+    if (p->kind == Plan::COLUMNS) {
+        rc = p->eng.build(p->n, p->batch, p->dtype, p->inner, p->fs_n, p->fs_c0);
+        if (rc) return rc;
+        p->workspace += p->eng.bytes;
+        p->launches = p->eng.launches();
+        return MFFT_OK;
+    }
     if (p->n == 1) {
         p->kind = Plan::ONE_POINT;
         if (p->flags & MFFT_DEMOD) MFFT_HIP(hipMalloc(&p->d_pre, 2 * real_size(p->dtype)));
@@ -688,6 +766,14 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
                            demod ? pre : (const cx<T>*)nullptr, (T)scale, inverse ? 1 : 0, power ? 1 : 0, stats);
         MFFT_HIP(hipGetLastError());
         return MFFT_OK;
+    }
+    if (p->kind == Plan::COLUMNS) {
+        if (scale != 1.0) { set_error("column-batched plans do not scale their output"); return MFFT_E_INVALID; }
+        Io<T> io;
+        io.in = d_in; io.out = d_out;
+        io.in_stride = io.out_stride = p->n * p->inner;
+        io.n_in = io.n_out = p->n;
+        return p->eng.exec<T>(io, s);
     }
     if (p->kind == Plan::POW2) {
         Io<T> io;
@@ -833,6 +919,32 @@ int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dty
     return mfft_plan_1d_layout(out, n, n_in, batch, dtype, flags, nullptr, nullptr);
 }
 
+int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
+                         int64_t twiddle_n, int64_t twiddle_c0)
+{
+    if (!out) { set_error("null plan pointer"); return MFFT_E_INVALID; }
+    *out = nullptr;
+    if (n < 1) { set_error("Invalid number of FFT data points (" + std::to_string(n) + ") specified."); return MFFT_E_INVALID; }
+    if (inner < 1 || batch < 1) { set_error("inner and batch must be >= 1"); return MFFT_E_INVALID; }
+    if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("dtype must be MFFT_C64 or MFFT_C128"); return MFFT_E_INVALID; }
+    if (twiddle_n < 0 || twiddle_c0 < 0) { set_error("bad twiddle description"); return MFFT_E_INVALID; }
+    if (!is_pow2(n) || n < (int64_t(1) << kTileMinLog2G)) {
+        set_error("column-batched plans serve power-of-two lengths >= 16");
+        return MFFT_E_UNSUPPORTED;
+    }
+    if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
+    Plan* p = new (std::nothrow) Plan;
+    if (!p) { set_error("host allocation failed"); return MFFT_E_NOMEM; }
+    p->kind = Plan::COLUMNS;
+    p->n = n; p->n_in = n; p->batch = batch; p->dtype = dtype; p->flags = 0;
+    p->inner = inner; p->fs_n = twiddle_n; p->fs_c0 = twiddle_c0;
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("hipGetDevice failed"); return MFFT_E_HIP; }
+    const int rc = plan_build(p);
+    if (rc != MFFT_OK) { plan_free(p); return rc; }
+    *out = reinterpret_cast<mfft_plan>(p);
+    return MFFT_OK;
+}
+
 int mfft_plan_destroy(mfft_plan plan)
 {
     if (!plan) return MFFT_OK;
@@ -880,8 +992,8 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
     std::lock_guard<std::mutex> lock(p->mu);
     const size_t rs = real_size(p->dtype);
-    const size_t in_bytes = (size_t)p->batch * (size_t)p->n_in * rs * ((p->flags & MFFT_REAL_IN) ? 1 : 2);
-    const size_t out_bytes = (size_t)p->batch * (size_t)p->n * rs * ((p->flags & MFFT_POWER) ? 1 : 2);
+    const size_t in_bytes = (size_t)p->batch * (size_t)p->n_in * (size_t)p->inner * rs * ((p->flags & MFFT_REAL_IN) ? 1 : 2);
+    const size_t out_bytes = (size_t)p->batch * (size_t)p->n * (size_t)p->inner * rs * ((p->flags & MFFT_POWER) ? 1 : 2);
     if (!p->d_in) MFFT_HIP(hipMalloc(&p->d_in, in_bytes));
     if (!p->d_out) MFFT_HIP(hipMalloc(&p->d_out, out_bytes));
     if ((p->flags & MFFT_STATS) && !p->d_stats)
@@ -1035,6 +1147,26 @@ int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, in
         hipLaunchKernelGGL(transpose_kernel<double>, grid, dim3(256), 0, s, static_cast<const cx<double>*>(d_in),
                            static_cast<cx<double>*>(d_out), rows, cols);
     else { set_error("bad dtype"); return MFFT_E_INVALID; }
+    MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int dtype, void* stream)
+{
+    if (!d_in || !d_out || a < 1 || b < 1 || w < 1 || d_in == d_out) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("bad dtype"); return MFFT_E_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rows = a * b;
+    const int64_t bytes_per_row = w * 2 * (int64_t)real_size(dtype);
+    const int block = bytes_per_row >= 4096 ? 256 : 64;      // 16 bytes per lane per trip
+    const int64_t cap = (int64_t)device_cu_count() * 32;
+    const unsigned grid = (unsigned)(rows < cap ? rows : cap);
+    if (dtype == MFFT_C64)
+        hipLaunchKernelGGL(swap_axes_kernel<float>, dim3(grid), dim3(block), 0, s, static_cast<const cx<float>*>(d_in),
+                           static_cast<cx<float>*>(d_out), a, b, w);
+    else
+        hipLaunchKernelGGL(swap_axes_kernel<double>, dim3(grid), dim3(block), 0, s, static_cast<const cx<double>*>(d_in),
+                           static_cast<cx<double>*>(d_out), a, b, w);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }

@@ -74,7 +74,16 @@ template <typename T> struct TArgs {
     int64_t n_out;        // LAST: bins stored per signal
     int64_t in_seg, in_seg_stride;     // FIRST: segmented input layout (0 = dense)
     int64_t out_seg, out_seg_stride;   // LAST: segmented output layout (0 = dense)
+    // LAST_TWID: out(k, c) *= exp(-2*pi*i * k*(tw_c0 + c) / tw_n), k = row, c = column of the
+    // (n x W) array (the four-step inter-step twiddle), from a two-level table like tw_lo/tw_hi
+    const cx<double>* fs_lo;
+    const cx<double>* fs_hi;
+    int64_t tw_c0;
+    uint64_t fs_mask;     // tw_n - 1 (tw_n is a power of two)
+    int fs_lb;
     int lb;
+    int log2_w;           // column-batched transforms: W = 1 << log2_w contiguous columns share every
+                          // butterfly (NS counts elements, i.e. includes W); 0 for ordinary signals
     int log2_ns;          // NS = 1 << log2_ns
     int log2_tiles;       // tiles per signal = (L / C) = 1 << log2_tiles
     int real_in, conj_in, conj_out;
@@ -86,7 +95,7 @@ template <typename T> struct TArgs {
 // inter-pass twiddle.  LAST_*: natural-order bins out.  *_PLAIN = dense full-length complex
 // data and nothing fused; *_GEN / LAST_POWER carry the runtime prologue / epilogue.
 enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN = 3, TM_LAST_GEN = 4,
-                TM_LAST_POWER = 5 };
+                TM_LAST_POWER = 5, TM_LAST_TWID = 6 };
 
 // Columns per tile: 256-byte rows where LDS allows (32 complex64 / 16 complex128 up to 256-point
 // columns), 128-byte rows for the 512-point tile (the largest: a 1024-point tile would need 1024
@@ -130,7 +139,6 @@ template <typename T, int LOG2G, int LOG2C, int MODE>
 __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel(const TArgs<T> a)
 {
     constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN);
-    constexpr bool LAST = (MODE == TM_LAST_PLAIN || MODE == TM_LAST_GEN || MODE == TM_LAST_POWER);
     using C_ = cx<T>;
     using TC = TileCfg<LOG2G>;
     using RD = typename TC::SC::RD;
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             }
         } else {
             const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
-            const uint32_t m = (uint32_t)(j & ns_mask);           // NS <= 2^30
+            const uint32_t m = (uint32_t)((j & ns_mask) >> a.log2_w);   // NS / W <= 2^30
             const C_* __restrict__ p = src + (int64_t)t * a.L;
             const int64_t pstep = (int64_t)TX * a.L;
             if (a.nt & 1) {
@@ -290,6 +298,30 @@ __global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel
             } else {
 #pragma unroll
                 for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+            }
+        } else if constexpr (MODE == TM_LAST_TWID) {
+            // last pass of a column-batched transform with the four-step twiddle folded in:
+            // row k = (j >> log2_w) + q*(NS >> log2_w), column cc = tw_c0 + (j & (W-1));
+            // exponent k*cc = base + q*step, built like the inter-pass twiddle above
+            const uint64_t cc = (uint64_t)(a.tw_c0 + (j & ((int64_t(1) << a.log2_w) - 1)));
+            const uint64_t nsr = (uint64_t)(a.NS >> a.log2_w);
+            const uint64_t kb = (((uint64_t)(j >> a.log2_w) + (uint64_t)t * nsr) * cc) & a.fs_mask;
+            const uint64_t ks = ((uint64_t)TX * nsr * cc) & a.fs_mask;
+            const uint64_t lomask = (uint64_t(1) << a.fs_lb) - 1;
+            const cx<double> bl = a.fs_lo[kb & lomask], bh = a.fs_hi[kb >> a.fs_lb];
+            const cx<double> sl = a.fs_lo[ks & lomask], sh = a.fs_hi[ks >> a.fs_lb];
+            cx<double> w = cmul(bl, bh);
+            const cx<double> step = cmul(sl, sh);
+            C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j + (int64_t)t * a.NS;
+            const int64_t qstep = (int64_t)TX * a.NS;
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const double xr = (double)v[e].x, xi = (double)v[e].y;
+                const C_ val{(T)(xr * w.x - xi * w.y), (T)(xr * w.y + xi * w.x)};
+                if (a.nt & 2) tile_st<T, true>(q, val);
+                else tile_st<T, false>(q, val);
+                q += qstep;
+                w = cmul(w, step);
             }
         } else if constexpr (MODE == TM_LAST_PLAIN) {
             // last pass: NS*G = N, so j < NS and bin k = j + q*NS
@@ -403,6 +435,7 @@ int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
     case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_LAST_PLAIN>(a, s);
     case TM_LAST_GEN: return launch_tile_one<T, LOG2G, LC, TM_LAST_GEN>(a, s);
     case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LC, TM_LAST_POWER>(a, s);
+    case TM_LAST_TWID: return launch_tile_one<T, LOG2G, LC, TM_LAST_TWID>(a, s);
     }
     set_error("unknown tile mode");
     return MFFT_E_INVALID;

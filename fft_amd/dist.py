@@ -27,7 +27,7 @@ import ctypes
 import threading
 
 from . import _lib
-from .engine import Plan
+from .engine import ColumnPlan, Plan
 
 
 # --------------------------------------------------------------------------- sharding
@@ -112,8 +112,35 @@ class HipOps:
                 self._plans[key] = plan
         plan.exec(src, dst, stream=self._stream())
 
+    def _column_plan(self, n, inner, batch, dtype, twiddle, device):
+        key = ("col", n, inner, batch, dtype, twiddle, device)
+        with self._lock:
+            if key not in self._plans:
+                try:
+                    self._plans[key] = ColumnPlan(n, inner, batch=batch, dtype=dtype, twiddle=twiddle)
+                except _lib.MfftError:
+                    self._plans[key] = None          # shape outside the tile passes' range
+            return self._plans[key]
+
+    def columns_ok(self, n, inner, like, batch=1):
+        """Whether fft_columns serves an (n x inner) array of this dtype."""
+        return self._column_plan(n, inner, batch, self._dtype_of(like), None, like.device.index) is not None
+
+    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None):
+        """dst[b][k][c] = sum_j src[b][j][c] exp(-2 pi i j k / n), times exp(-2 pi i k (c0 + c) / n_total)
+        when twiddle = (n_total, c0); the columns are transformed where they lie."""
+        plan = self._column_plan(n, inner, batch, self._dtype_of(src), twiddle, src.device.index)
+        if plan is None:
+            raise _lib.MfftError(f"no column-batched plan for n={n}, inner={inner}")
+        plan.exec(src, dst, stream=self._stream())
+
     def transpose(self, src, dst, rows, cols, batch=1):
         _lib.check(_lib.load().mfft_transpose(src.data_ptr(), dst.data_ptr(), rows, cols, batch,
+                                              self._dtype_of(src), self._stream() or None))
+
+    def swap_axes(self, src, dst, a, b, w):
+        """dst viewed as (b, a, w) = src viewed as (a, b, w) with the two leading axes swapped."""
+        _lib.check(_lib.load().mfft_swap_axes(src.data_ptr(), dst.data_ptr(), a, b, w,
                                               self._dtype_of(src), self._stream() or None))
 
     def twiddle(self, x, rows, cols, r0, c0, n_total):
@@ -123,8 +150,22 @@ class HipOps:
     def close(self):
         with self._lock:
             for p in self._plans.values():
-                p.destroy()
+                if p is not None:
+                    p.destroy()
             self._plans.clear()
+
+
+class _Buffers:
+    """Two scratch buffers of the local size; `free(*busy)` hands out one that is none of `busy`."""
+
+    def __init__(self, ops, count, like):
+        self._bufs = [ops.empty(count, like), ops.empty(count, like)]
+
+    def free(self, *busy):
+        for b in self._bufs:
+            if all(b is not t for t in busy):
+                return b
+        raise RuntimeError("no free scratch buffer")
 
 
 # --------------------------------------------------------------------------- 2-D slab / pencil
@@ -135,10 +176,14 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
     ``a_local``: this rank's n0/P consecutive rows, flat complex tensor of (n0/P)*n1
     elements (row-major).  Returns a flat tensor of the same size:
 
-    * ``restore_layout=False`` (one all-to-all): the TRANSPOSED spectrum in column
-      slabs -- out[c*n0 + k0] = F[k0][rank*(n1/P) + c];
+    * ``restore_layout=False`` (one all-to-all): the spectrum in column slabs, all n0 rows
+      of this rank's n1/P columns -- out[k0*(n1/P) + c] = F[k0][rank*(n1/P) + c];
     * ``restore_layout=True`` (two all-to-alls): the spectrum in the input's own row-slab
       layout -- out[i*n1 + k1] = F[rank*(n0/P) + i][k1].
+
+    Local passes over the slab: row FFTs (stored already packed per destination), then the
+    column FFTs on the strided columns where the exchange left them (no transpose), then --
+    only with P > 1 and restore_layout -- one block copy that unpacks the way back.
     """
     P = comm.world
     if n0 % P or n1 % P:
@@ -146,27 +191,31 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
     R, W = n0 // P, n1 // P
     if a_local.numel() != R * n1:
         raise ValueError("a_local has the wrong size for this rank's slab")
-    x = ops.empty(R * n1, a_local)
-    y = ops.empty(R * n1, a_local)
-
-    def other(t):
-        return y if t is x else x
+    bufs = _Buffers(ops, R * n1, a_local)
 
     # row FFTs; bin k of local row i is stored at [k // W][i][k % W]: already packed per destination
+    x = bufs.free(a_local)
     ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
-    cur = comm.all_to_all(y, x)                    # cur[r][i][c]: an (n0 x W) matrix [global row][local col]
-    nxt = other(cur)
-    ops.transpose(cur, nxt, rows=n0, cols=W)       # -> (W x n0): each local column contiguous
-    cur, nxt = nxt, cur
+    cur = comm.all_to_all(bufs.free(x), x)         # cur[r][i][c]: (n0 x W), row r*R + i, local column c
+    nxt = bufs.free(cur)
+    if ops.columns_ok(n0, W, cur):
+        ops.fft_columns(cur, nxt, n=n0, inner=W)
+        cur = nxt
+    else:                                          # shapes outside the tile passes: go through a transpose
+        ops.transpose(cur, nxt, rows=n0, cols=W)   # (W x n0)
+        ops.fft(nxt, cur, n=n0, batch=W)
+        ops.transpose(cur, nxt, rows=W, cols=n0)   # (n0 x W)
+        cur = nxt
+    # cur[k0][c] = F[k0][rank*W + c]
     if not restore_layout:
-        ops.fft(cur, nxt, n=n0, batch=W)
-        return nxt
-    # column FFTs; bin k0 of local column c goes to [k0 // R][c][k0 % R], packed for the way back
-    ops.fft(cur, nxt, n=n0, batch=W, out_layout=(R, R, W * R))
-    cur = comm.all_to_all(cur, nxt)                # cur[s][c][i]: an (n1 x R) matrix [global col][local row]
-    nxt = other(cur)
-    ops.transpose(cur, nxt, rows=n1, cols=R)       # -> (R x n1)
-    return nxt
+        return cur
+    # rows [s*R, (s+1)*R) belong to rank s: the per-destination chunks are already contiguous
+    res = comm.all_to_all(bufs.free(cur), cur)     # res[s][i][c] = F[rank*R + i][s*W + c]
+    if P == 1:
+        return res
+    out = bufs.free(res)
+    ops.swap_axes(res, out, a=P, b=R, w=W)         # out[i][s][c]: (R x n1)
+    return out
 
 
 # --------------------------------------------------------------------------- large 1-D four-step
@@ -183,6 +232,11 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
 
     * ``natural_order=True`` (three all-to-alls): X[rank*n/P + m];
     * ``natural_order=False`` (two all-to-alls): out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2].
+
+    Local passes: one block copy that packs the first exchange, the n1-point FFTs on the
+    strided columns with the inter-step twiddle folded into their last store, the n2-point
+    FFTs reading the second exchange's blocks in place (segmented load), and for natural
+    order one transpose after the third exchange.
     """
     P = comm.world
     if n1 % P or n2 % P:
@@ -191,31 +245,38 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
     R1, W2 = n1 // P, n2 // P
     if x_local.numel() != R1 * n2:
         raise ValueError("x_local has the wrong size for this rank's chunk")
-    x = ops.empty(R1 * n2, x_local)
-    y = ops.empty(R1 * n2, x_local)
+    bufs = _Buffers(ops, R1 * n2, x_local)
 
-    def other(t):
-        return y if t is x else x
-
-    # local rows j1 (R1 x n2) -> (n2 x R1): destination s owns rows [s*W2, (s+1)*W2), contiguous
-    ops.transpose(x_local, x, rows=R1, cols=n2)
-    cur = comm.all_to_all(y, x)                    # cur[r][c][i] = x[(r*R1 + i)*n2 + rank*W2 + c]
-    nxt = other(cur)
-    # n1-point FFT over j1 for each local column c.  Sample j1 sits at [j1 // R1][c][j1 % R1];
-    # bin k1 is stored at [k1 // R1][c][k1 % R1], i.e. packed for the owner of that k1 block.
-    seg = (R1, R1, W2 * R1)
-    ops.fft(cur, nxt, n=n1, batch=W2, in_layout=seg, out_layout=seg)
-    cur = comm.all_to_all(cur, nxt)                # cur[s][c][i] = A[j2 = s*W2 + c][k1 = rank*R1 + i]: (n2 x R1)
-    nxt = other(cur)
-    ops.twiddle(cur, rows=n2, cols=R1, r0=0, c0=comm.rank * R1, n_total=n)
-    ops.transpose(cur, nxt, rows=n2, cols=R1)      # -> (R1 x n2): each local k1 row contiguous in j2
-    cur, nxt = nxt, cur
+    # pack: local rows j1 (R1 x P x W2) -> [s][i][c]; destination s owns columns [s*W2, (s+1)*W2)
+    if P == 1:
+        cur = x_local
+    else:
+        x = bufs.free(x_local)
+        ops.swap_axes(x_local, x, a=R1, b=P, w=W2)
+        cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
+    nxt = bufs.free(cur)
+    if ops.columns_ok(n1, W2, cur):
+        # A[k1][c] = W_n^(k1 * (rank*W2 + c)) * sum_j1 W_n1^(j1 k1) cur[j1][c]
+        ops.fft_columns(cur, nxt, n=n1, inner=W2, twiddle=(n, comm.rank * W2))
+        cur = nxt
+    else:
+        ops.transpose(cur, nxt, rows=n1, cols=W2)  # (W2 x n1): each local column contiguous
+        tmp = bufs.free(nxt, x_local)
+        ops.fft(nxt, tmp, n=n1, batch=W2)
+        ops.twiddle(tmp, rows=W2, cols=n1, r0=comm.rank * W2, c0=0, n_total=n)
+        cur = bufs.free(tmp, x_local)
+        ops.transpose(tmp, cur, rows=W2, cols=n1)  # (n1 x W2)
+    # rows k1 in [s*R1, (s+1)*R1) belong to rank s: chunks already contiguous
+    res = comm.all_to_all(bufs.free(cur, x_local), cur)   # res[s][i][c] = A[k1 = rank*R1 + i][j2 = s*W2 + c]
+    out = bufs.free(res, x_local)
+    # n2-point FFT over j2 for each local row i: sample j2 sits at [j2 // W2][i][j2 % W2]
+    seg_in = (W2, W2, R1 * W2)
     if not natural_order:
-        ops.fft(cur, nxt, n=n2, batch=R1)
-        return nxt
-    # n2-point FFT over j2; bin k2 of local row i goes to [k2 // W2][i][k2 % W2] (owner of natural index k2*n1 + k1)
-    ops.fft(cur, nxt, n=n2, batch=R1, out_layout=(W2, W2, R1 * W2))
-    cur = comm.all_to_all(cur, nxt)                # cur[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
-    nxt = other(cur)
-    ops.transpose(cur, nxt, rows=n1, cols=W2)      # -> (W2 x n1) = natural-order chunk
-    return nxt
+        ops.fft(res, out, n=n2, batch=R1, in_layout=seg_in)
+        return out
+    # bin k2 of local row i goes to [k2 // W2][i][k2 % W2] (owner of natural index k2*n1 + k1)
+    ops.fft(res, out, n=n2, batch=R1, in_layout=seg_in, out_layout=seg_in)
+    res = comm.all_to_all(bufs.free(out, x_local), out)   # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
+    out = bufs.free(res, x_local)
+    ops.transpose(res, out, rows=n1, cols=W2)      # -> (W2 x n1) = natural-order chunk
+    return out

@@ -149,3 +149,38 @@ class Plan:
 
     def __exit__(self, *exc):
         self.destroy()
+
+
+class ColumnPlan(Plan):
+    """Column-batched transform (mfft_plan_1d_columns): np.fft.fft(a, axis=-2) on a
+    (batch, n, inner) array, on the strided columns where they lie.  ``twiddle=(n_total, c0)``
+    also multiplies output (k, c) by exp(-2 pi i k (c0 + c) / n_total).  Raises MfftError
+    for shapes the tile passes do not serve (callers then transpose and use Plan)."""
+
+    def __init__(self, n: int, inner: int, batch: int = 1, dtype: int = _lib.C64, twiddle=None):
+        lib = _lib.load()
+        self.n = self.n_in = int(n)
+        self.inner = int(inner)
+        self.batch = int(batch)
+        self.dtype = int(dtype)
+        self.flags = 0
+        self._h = ctypes.c_void_p()
+        tw_n, tw_c0 = (int(twiddle[0]), int(twiddle[1])) if twiddle is not None else (0, 0)
+        _lib.check(lib.mfft_plan_1d_columns(ctypes.byref(self._h), self.n, self.inner, self.batch,
+                                            self.dtype, tw_n, tw_c0))
+        self._lock = threading.Lock()
+
+    def exec_host(self, x: np.ndarray):
+        """Synchronous execution on a numpy array of batch*n*inner complex elements."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        x = np.ascontiguousarray(x, dtype=self.complex_dtype)
+        if x.size != self.batch * self.n * self.inner:
+            raise ValueError(f"input has {x.size} elements, plan expects {self.batch}x{self.n}x{self.inner}")
+        out = np.empty(x.shape, dtype=self.complex_dtype)
+        with self._lock:
+            _lib.check(_lib.load().mfft_exec_host(self._h, x.ctypes.data, out.ctypes.data, 1.0, 0.0, 0.0, 1.0, None))
+        return out
+
+    def exec_host_peaks(self, *a, **k):
+        raise ValueError("column-batched plans have no spectrum scan")

@@ -89,6 +89,20 @@ typedef struct mfft_layout {
 } mfft_layout;
 int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dtype, uint32_t flags,
                         const mfft_layout* in_layout, const mfft_layout* out_layout);
+
+/* Column-batched plan: np.fft.fft(a, axis=-2) on a (batch, n, inner) array whose last axis is
+ * contiguous -- every butterfly is shared by `inner` adjacent columns, so the transform runs
+ * on the strided columns where they lie (coalesced tiles of 256-byte rows) and no transpose
+ * pass exists.  This is the column step of np.fft.fft2 (BASELINE config 4) and the strided
+ * steps of the four-step split of one long np.fft.fft (config 5).  n: a power of two >= 16;
+ * inner: a power of two >= 32 (complex64) / 16 (complex128); other shapes return
+ * MFFT_E_UNSUPPORTED (callers fall back to mfft_transpose + mfft_plan_1d).  Plain complex in
+ * and out, executed with mfft_exec (scale must be 1) or mfft_exec_host.
+ * twiddle_n > 0 (a power of two) additionally multiplies output element (k, c) by
+ * exp(-2*pi*i * k*(twiddle_c0 + c) / twiddle_n): the inter-step twiddle of the four-step
+ * algorithm, folded into the last pass' store. */
+int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
+                         int64_t twiddle_n, int64_t twiddle_c0);
 int mfft_plan_destroy(mfft_plan plan);
 
 /* Bytes of device workspace the plan holds, and the number of kernel launches
@@ -159,6 +173,12 @@ int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const do
  * (local re-layout step of the pencil / four-step decompositions). */
 int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, int64_t batch,
                    int dtype, void* stream);
+
+/* out[j][i][:] = in[i][j][:]  for an (a, b, w) array of complex elements with the last axis
+ * contiguous: the pack / unpack of an all-to-all exchange whose per-peer blocks are rows of w
+ * elements (np.swapaxes(x.reshape(a, b, w), 0, 1) made contiguous). */
+int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int dtype,
+                   void* stream);
 
 /* x[r][c] *= exp(-2*pi*i * (r0 + r)*(c0 + c) / n_total)  on a rows x cols complex tile
  * (the inter-step twiddle of the four-step algorithm). */

@@ -21,7 +21,30 @@ def layout_index(n, batch, layout, dense_stride):
 
 
 class NumpyOps:
-    """CPU stand-in: numpy's FFT as the local engine (the oracle's arithmetic)."""
+    """CPU stand-in: numpy's FFT as the local engine (the oracle's arithmetic).
+    `columns=False` makes it decline column-batched transforms, which drives the
+    decompositions down their transpose fallback."""
+
+    def __init__(self, columns=True):
+        self.columns = columns
+
+    def columns_ok(self, n, inner, like, batch=1):
+        return self.columns
+
+    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None):
+        assert self.columns
+        x = src.numpy()[: batch * n * inner].reshape(batch, n, inner)
+        y = np.fft.fft(x, axis=1)
+        if twiddle is not None:
+            n_total, c0 = twiddle
+            k = np.arange(n, dtype=np.int64)[:, None]
+            c = (c0 + np.arange(inner, dtype=np.int64))[None, :]
+            y = y * np.exp(-2j * np.pi * ((k * c) % n_total) / n_total)[None]
+        dst.numpy()[: batch * n * inner] = y.reshape(-1)
+
+    def swap_axes(self, src, dst, a, b, w):
+        x = src.numpy()[: a * b * w].reshape(a, b, w)
+        dst.numpy()[: a * b * w] = x.transpose(1, 0, 2).reshape(-1)
 
     def empty(self, count, like):
         import torch
@@ -73,30 +96,37 @@ def worker(rank, world, port, use_gpu, results_dir):
         assert comm.world == world and comm.rank == rank
         errs = {}
 
-        # ---- 2-D slab -------------------------------------------------------------
-        n0, n1 = 64, 96 if not use_gpu else 128
-        A = global_inputs(1, (n0, n1))
-        F = np.fft.fft2(A)
-        R, W = n0 // world, n1 // world
-        mine = torch.from_numpy(A[rank * R:(rank + 1) * R].reshape(-1).copy()).to(dev)
-        out = fd.fft2_slab(mine, n0, n1, comm, ops, restore_layout=False).cpu().numpy().reshape(W, n0)
-        errs["fft2_T"] = rel_l2(out, F[:, rank * W:(rank + 1) * W].T)
-        out = fd.fft2_slab(mine, n0, n1, comm, ops, restore_layout=True).cpu().numpy().reshape(R, n1)
-        errs["fft2_N"] = rel_l2(out, F[rank * R:(rank + 1) * R])
+        # on the CPU stand-in run both the column-batched route and the transpose fallback; on
+        # the GPU the shapes pick the route: (64 x 128), 32*64 -> tile passes, (8 x 128), 8*64 -> fallback
+        variants = [("col", NumpyOps(columns=True)), ("tr", NumpyOps(columns=False))] if not use_gpu \
+            else [("gpu", ops)]
+        for tag, vops in variants:
+            for n0, n1 in ((64, 96 if not use_gpu else 128), (8, 128)):
+                # ---- 2-D slab ---------------------------------------------------------
+                A = global_inputs(1, (n0, n1))
+                F = np.fft.fft2(A)
+                R, W = n0 // world, n1 // world
+                mine = torch.from_numpy(A[rank * R:(rank + 1) * R].reshape(-1).copy()).to(dev)
+                out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False).cpu().numpy().reshape(n0, W)
+                errs[f"fft2_cols_{tag}_{n0}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
+                out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True).cpu().numpy().reshape(R, n1)
+                errs[f"fft2_rows_{tag}_{n0}"] = rel_l2(out, F[rank * R:(rank + 1) * R])
+                assert np.array_equal(mine.cpu().numpy(), A[rank * R:(rank + 1) * R].reshape(-1)), "input clobbered"
 
-        # ---- 1-D four-step ---------------------------------------------------------
-        n1f, n2f = 32, 64
-        n = n1f * n2f
-        x = global_inputs(2, (n,))
-        X = np.fft.fft(x)
-        chunk = n // world
-        mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
-        out = fd.fft1d_fourstep(mine, n1f, n2f, comm, ops, natural_order=True).cpu().numpy()
-        errs["fft1d_N"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
-        out = fd.fft1d_fourstep(mine, n1f, n2f, comm, ops, natural_order=False).cpu().numpy()
-        R1 = n1f // world
-        want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
-        errs["fft1d_T"] = rel_l2(out.reshape(R1, n2f), want)
+            # ---- 1-D four-step ---------------------------------------------------------
+            for n1f, n2f in ((32, 64), (8, 64)):
+                n = n1f * n2f
+                x = global_inputs(2, (n,))
+                X = np.fft.fft(x)
+                chunk = n // world
+                mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
+                out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True).cpu().numpy()
+                errs[f"fft1d_N_{tag}_{n1f}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
+                out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=False).cpu().numpy()
+                R1 = n1f // world
+                want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
+                errs[f"fft1d_T_{tag}_{n1f}"] = rel_l2(out.reshape(R1, n2f), want)
+                assert np.array_equal(mine.cpu().numpy(), x[rank * chunk:(rank + 1) * chunk]), "input clobbered"
 
         # ---- batch sharding: no collective ------------------------------------------
         lo, hi = fd.shard_range(37, world, rank)

@@ -52,13 +52,17 @@ def test_single_rank_cpu_standin():
     """world_size 1 degenerates to local copies: same code path, no process group."""
     import torch
     from fft_amd import dist as fd
-    comm, ops = fd.Comm(), dh.NumpyOps()
-    A = dh.global_inputs(5, (16, 24))
-    out = fd.fft2_slab(torch.from_numpy(A.reshape(-1).copy()), 16, 24, comm, ops, restore_layout=True)
-    assert dh.rel_l2(out.numpy().reshape(16, 24), np.fft.fft2(A)) < 1e-12
-    x = dh.global_inputs(6, (8 * 32,))
-    out = fd.fft1d_fourstep(torch.from_numpy(x.copy()), 8, 32, comm, ops)
-    assert dh.rel_l2(out.numpy(), np.fft.fft(x)) < 1e-12
+    comm = fd.Comm()
+    for ops in (dh.NumpyOps(columns=True), dh.NumpyOps(columns=False)):
+        A = dh.global_inputs(5, (16, 24))
+        for restore in (True, False):          # one rank: both layouts are the plain (16 x 24) spectrum
+            out = fd.fft2_slab(torch.from_numpy(A.reshape(-1).copy()), 16, 24, comm, ops, restore_layout=restore)
+            assert dh.rel_l2(out.numpy().reshape(16, 24), np.fft.fft2(A)) < 1e-12
+        x = dh.global_inputs(6, (8 * 32,))
+        out = fd.fft1d_fourstep(torch.from_numpy(x.copy()), 8, 32, comm, ops)
+        assert dh.rel_l2(out.numpy(), np.fft.fft(x)) < 1e-12
+        out = fd.fft1d_fourstep(torch.from_numpy(x.copy()), 8, 32, comm, ops, natural_order=False)
+        assert dh.rel_l2(out.numpy().reshape(8, 32), np.fft.fft(x).reshape(32, 8).T) < 1e-12
 
 
 @pytest.mark.gpu
@@ -68,15 +72,16 @@ def test_single_gpu_real_kernels(dtype, tol):
     from fft_amd import dist as fd
     torch.cuda.set_device(0)
     comm, ops = fd.Comm(), fd.HipOps()
-    for n0, n1 in ((256, 512), (1024, 64), (2048, 2048)):
+    for n0, n1 in ((256, 512), (1024, 64), (2048, 2048), (8, 64), (48, 80)):
         A = dh.global_inputs(n0 + n1, (n0, n1), dtype)
         ref = np.fft.fft2(A.astype(np.complex128))
         d = torch.from_numpy(A.reshape(-1).copy()).cuda()
         out = fd.fft2_slab(d, n0, n1, comm, ops, restore_layout=True)
         assert dh.rel_l2(out.cpu().numpy().reshape(n0, n1), ref) < tol
         out = fd.fft2_slab(d, n0, n1, comm, ops, restore_layout=False)
-        assert dh.rel_l2(out.cpu().numpy().reshape(n1, n0), ref.T) < tol
-    for n1, n2 in ((64, 128), (1024, 1024), (4096, 256)):
+        assert dh.rel_l2(out.cpu().numpy().reshape(n0, n1), ref) < tol
+        assert np.array_equal(d.cpu().numpy(), A.reshape(-1))          # input untouched
+    for n1, n2 in ((64, 128), (1024, 1024), (4096, 256), (8, 16), (1 << 17, 64)):
         x = dh.global_inputs(n1 * 3 + n2, (n1 * n2,), dtype)
         ref = np.fft.fft(x.astype(np.complex128))
         out = fd.fft1d_fourstep(torch.from_numpy(x.copy()).cuda(), n1, n2, comm, ops)

@@ -100,3 +100,32 @@ def test_real_input_chirpz_and_one_point(fa):
         S, st = p.exec_host(x1, scale=2.0)
     assert np.allclose(S[:, 0], np.abs(2.0 * x1[:, 0]) ** 2, rtol=1e-14)
     assert np.allclose(st[:, 0], S[:, 0]) and np.allclose(st[:, 2], 0.0)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_column_batched_plans(fa, dtype):
+    """np.fft.fft(a, axis=-2) on the strided columns (no transpose pass), one to three tile
+    passes, with and without the fused four-step twiddle."""
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    wmin = 32 if dtype == 0 else 16
+    for batch, n, inner in ((1, 16, wmin), (2, 256, wmin), (3, 1024, 64), (1, 16384, 64), (1, 1 << 19, wmin),
+                            (2, 64, 2048)):
+        x = _rand((batch, n, inner), n + inner + dtype, cdt)
+        with fa.ColumnPlan(n, inner, batch=batch, dtype=dtype) as p:
+            assert p.launches == (1 if n <= 512 else (2 if n <= 1 << 18 else 3))
+            y = p.exec_host(x)
+        ref = np.fft.fft(x.astype(np.complex128), axis=1)
+        assert rel_l2(y, ref) < TOL[dtype], (batch, n, inner)
+    # fused inter-step twiddle of the four-step algorithm
+    n, inner, c0, n_total = 1024, 128, 384, 1024 * 4096
+    x = _rand((1, n, inner), 99, cdt)
+    with fa.ColumnPlan(n, inner, dtype=dtype, twiddle=(n_total, c0)) as p:
+        y = p.exec_host(x)
+    k = np.arange(n)[:, None].astype(np.float64)
+    c = (c0 + np.arange(inner))[None, :].astype(np.float64)
+    ref = np.fft.fft(x[0].astype(np.complex128), axis=0) * np.exp(-2j * np.pi * (k * c) / n_total)
+    assert rel_l2(y[0], ref) < TOL[dtype]
+    # shapes the tile passes do not serve are refused, not mis-computed
+    for n, inner in ((8, 64), (48, 64), (64, 8), (64, 48)):
+        with pytest.raises(fa.MfftError):
+            fa.ColumnPlan(n, inner, dtype=dtype)
