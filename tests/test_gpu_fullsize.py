@@ -1,0 +1,111 @@
+"""BASELINE configurations 4 and 5 at their full sizes on one GPU (the single-rank case of
+the multi-GPU decompositions), checked through size-independent properties: a host
+transform of 2^31 points is out of reach, so random input is checked on sampled bins against
+the definition of the DFT evaluated directly in float64 (exact integer reduction of j*k mod n,
+one pass over the input per bin, torch on the device as the calculator), plus Parseval.
+Tolerances as in BASELINE.json: 1e-5 (complex64), 1e-12 (complex128), relative to the
+root-mean-square bin magnitude."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _energy(t, chunk=1 << 27):
+    """sum |t|^2 in float64 without a full-size temporary."""
+    import torch
+    r = torch.view_as_real(t).reshape(-1)
+    total = 0.0
+    for lo in range(0, r.numel(), chunk):
+        part = r[lo:lo + chunk].double()
+        total += float(torch.sum(part * part).item())
+    return total
+
+
+def _direct_bins_1d(x, ks, chunk=1 << 26):
+    """X[k] = sum_j x[j] exp(-2 pi i j k / n) for the given bins, float64 accumulation."""
+    import torch
+    n = x.numel()
+    out = []
+    for k in ks:
+        acc = torch.zeros((), dtype=torch.complex128, device=x.device)
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            j = torch.arange(lo, hi, dtype=torch.int64, device=x.device)
+            frac = ((j * int(k)) % n).to(torch.float64) / n          # exact: j*k < 2^62
+            ang = -2.0 * math.pi * frac
+            w = torch.complex(torch.cos(ang), torch.sin(ang))
+            acc = acc + torch.sum(x[lo:hi].to(torch.complex128) * w)
+            del j, frac, ang, w
+        out.append(complex(acc.item()))
+    return np.array(out)
+
+
+def test_cfg5_one_signal_2pow31_c128():
+    """BASELINE config 5 (N = 2^31 complex128, 32 GiB) through the four-step decomposition."""
+    import torch
+    from fft_amd import dist as fd
+    torch.cuda.set_device(0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 180 * (1 << 30):
+        pytest.skip("needs about 170 GiB of free device memory")
+    n1, n2 = 1 << 16, 1 << 15
+    n = n1 * n2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty(n, dtype=torch.complex128, device="cuda")
+    xr = torch.view_as_real(x)
+    for lo in range(0, n, 1 << 27):                                 # chunked: bounded temporaries
+        xr[lo:lo + (1 << 27)].normal_(generator=g)
+    e_in = _energy(x)
+    comm, ops = fd.Comm(), fd.HipOps()
+    try:
+        y = fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True)
+        torch.cuda.synchronize()
+        e_out = _energy(y)
+        assert abs(e_out / (n * e_in) - 1.0) < 1e-12                # Parseval
+        ks = [0, 1, 2, n1 - 1, n1, n1 + 1, n // 2 - 1, n // 2, n - n2, n - 1, 1234567891, 987654321]
+        got = y[torch.tensor(ks, device="cuda")].cpu().numpy()
+        del y
+        ops.close()
+        torch.cuda.empty_cache()
+        want = _direct_bins_1d(x, ks)
+        rms = math.sqrt(n * e_in / n)                               # root-mean-square |X[k]|
+        assert np.max(np.abs(got - want)) / rms < 1e-12
+    finally:
+        ops.close()
+
+
+def test_cfg4_2d_16384_c64():
+    """BASELINE config 4 (16384 x 16384 complex64, 2 GiB) through the slab decomposition."""
+    import torch
+    from fft_amd import dist as fd
+    torch.cuda.set_device(0)
+    n = 16384
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = torch.view_as_complex(torch.randn((n * n, 2), dtype=torch.float32, device="cuda", generator=g))
+    comm, ops = fd.Comm(), fd.HipOps()
+    try:
+        e_in = _energy(a)
+        for restore in (False, True):                               # one rank: same (n x n) spectrum either way
+            f = fd.fft2_slab(a, n, n, comm, ops, restore_layout=restore).view(n, n)
+            torch.cuda.synchronize()
+            e_out = _energy(f)
+            assert abs(e_out / (float(n) * n * e_in) - 1.0) < 1e-5
+            a2 = a.view(n, n)
+            j = torch.arange(n, dtype=torch.int64, device="cuda")
+            rms = math.sqrt(e_in)
+            worst = 0.0
+            for k0, k1 in ((0, 0), (1, 0), (0, 1), (127, 128), (128, 127), (8191, 8192), (16383, 16383),
+                           (12345, 6789), (4096, 1), (1, 4096)):
+                w1 = torch.exp(-2j * math.pi * ((j * k1) % n).double() / n)
+                w0 = torch.exp(-2j * math.pi * ((j * k0) % n).double() / n)
+                rows = torch.zeros(n, dtype=torch.complex128, device="cuda")
+                for lo in range(0, n, 2048):                        # A @ w1 in float64, 2048 rows at a time
+                    rows[lo:lo + 2048] = a2[lo:lo + 2048].to(torch.complex128) @ w1
+                want = complex(torch.dot(w0, rows).item())
+                worst = max(worst, abs(complex(f[k0, k1].item()) - want) / rms)
+            assert worst < 1e-5, worst
+    finally:
+        ops.close()
