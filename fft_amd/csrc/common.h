@@ -62,6 +62,9 @@ template <typename T> struct KArgs {
     int conj_in;           // conjugate on load  (inverse transform = conj . forward . conj)
     int conj_out;          // conjugate on store
     T scale;
+    // V_SEG: power-of-two segments as shifts.  Element j sits at (j >> lseg) * seg_stride +
+    // (j & ((1 << lseg) - 1)); lseg = 30 describes a dense signal.
+    int in_lseg, out_lseg;
 };
 
 // kernel variants
@@ -70,7 +73,8 @@ enum Variant {
     V_HANN_POWER = 1,  // complex in * register-resident window -> power out   (BASELINE config 2)
     V_GEN_CPLX = 2,    // general prologue (pad / window / premultiplier / real / conj) -> complex out
     V_GEN_POWER = 3,   // general prologue -> power out (+ optional per-signal stats)
-    V_COUNT = 4
+    V_SEG = 4,         // V_PLAIN over power-of-two segmented layouts (exchange packing of the multi-GPU paths)
+    V_COUNT = 5
 };
 
 // Description of how one power-of-two length is decomposed inside the LDS kernel.

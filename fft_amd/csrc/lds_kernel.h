@@ -268,6 +268,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
     using C = cx<T>;
     constexpr int N = RD::n;
     constexpr int TX = N / P;
+    constexpr int LOG2TX = __builtin_ctz(TX);
     constexpr int SLOTS = BLOCK / TX;
     constexpr int NPASS = RD::npass;
     constexpr int LDS_ELEMS = ((lds_pad<PADSHIFT>(N - 1) + 1 + 1) / 2) * 2;   // keep slots 16-byte aligned
@@ -315,7 +316,19 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
         C v[P];
 
         // ---- load (pass-0 inputs: positions t + TX*e) ----------------------
-        if constexpr (!GENERAL) {
+        if constexpr (VAR == V_SEG) {
+            const int64_t bl = active ? b : a.batch - 1;
+            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
+            // segments hold a whole number of TX-element rows (seg = TX << q), so the segment of
+            // element t + TX*e is e >> q for every lane: the offsets are wave-uniform (scalar
+            // registers) and one lane-dependent address serves all P accesses
+            const int q = a.in_lseg - LOG2TX;
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int64_t off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
+                v[e] = ld_stream(src + off + t);
+            }
+        } else if constexpr (!GENERAL) {
             // a slot beyond the batch re-reads the last signal and skips its stores: no branch here
             const int64_t bl = active ? b : a.batch - 1;
             const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
@@ -495,6 +508,13 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                             if (t + TX * e < a.n_out) dst[t + TX * e] = v[e];
                         }
                     }
+                } else if constexpr (VAR == V_SEG) {
+                    const int q = a.out_lseg - LOG2TX;
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
+                        const int64_t off = (int64_t)(e >> q) * a.out_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
+                        st_stream(dst + off + t, v[e]);
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, v[e]);
@@ -579,6 +599,7 @@ int launch_variant(int variant, const KArgs<T>& a, int grid, hipStream_t s)
     case V_HANN_POWER: return launch_one<T, LOG2N, V_HANN_POWER>(a, grid, s);
     case V_GEN_CPLX: return launch_one<T, LOG2N, V_GEN_CPLX>(a, grid, s);
     case V_GEN_POWER: return launch_one<T, LOG2N, V_GEN_POWER>(a, grid, s);
+    case V_SEG: return launch_one<T, LOG2N, V_SEG>(a, grid, s);
     }
     set_error("unknown kernel variant");
     return MFFT_E_INVALID;

@@ -7,17 +7,24 @@
 What runs where.  The window, zero padding, demodulation, forward transform,
 ``dt`` scaling, power spectrum and the max / centroid reductions run on the GPU
 as one fused plan (final2.py:139-146, streamlit_app_combined.py:199-215); the
-float64 power spectrum comes back once.  The O(#peaks) tail -- local-maximum
-scan, guard-spaced pick, log-parabolic refinement and the k <= 6 column least
-squares -- stays on the host in numpy, as does the (tiny) eigendecomposition that
-generates f(t) for ``fft_extract_E_p``.
+float64 power spectrum comes back once, together with the indices of its local
+maxima (scanned on the device).  The tall reductions of the tail also run on the
+GPU: the return-amplitude generator f(t) (final2.py:85-97) and the normal
+equations of the windowed least squares, including all 2^k fits of the sign
+search (final2.py:174-175, streamlit_app_combined.py:233-246).  What stays on the
+host is O(#peaks) scalar work: ranking the candidates, the guard-spaced pick, the
+log-parabolic refinement, k x k solves, and the eigendecomposition of the L <= 10
+block.
 
 There is no CPU fallback for the transform: without libmfft.so or without a GPU
 these functions raise.
 """
 from __future__ import annotations
 
+import ctypes
 import itertools
+import threading
+from collections import OrderedDict
 
 import numpy as np
 
@@ -25,6 +32,28 @@ from . import _lib
 from .npfft import cached_plan, engine_dtype, fftfreq
 
 TWO_PI = 2.0 * np.pi
+
+_axis_cache: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+_axis_lock = threading.Lock()
+
+
+def _omega_axis(nfft: int, dt: float) -> np.ndarray:
+    """2*pi*fftfreq(nfft, d=dt) (final2.py:144), kept for the few (nfft, dt) pairs an app
+    session cycles through: three passes over nfft doubles otherwise repeated on every
+    call.  The cached array is read-only; callers hand out copies (or its negation)."""
+    key = (int(nfft), float(dt))
+    with _axis_lock:
+        ax = _axis_cache.get(key)
+        if ax is not None:
+            _axis_cache.move_to_end(key)
+            return ax
+    ax = TWO_PI * fftfreq(nfft, d=dt)
+    ax.setflags(write=False)
+    with _axis_lock:
+        _axis_cache[key] = ax
+        while len(_axis_cache) > 8:
+            _axis_cache.popitem(last=False)
+    return ax
 
 
 # --------------------------------------------------------------------------- device part
@@ -87,6 +116,44 @@ def _window_of(f_t, use_hann):
     return np.hanning(len(f_t)) if use_hann else np.ones_like(f_t)
 
 
+def _normal_equations(x, win, times, E_cols, mu=0.0):
+    """(G, r, yy) of the windowed line fit, reduced on the GPU (mfft_lsq_normal_host):
+    G = B^H B, r = B^H y, yy = y^H y for B[:, a] = win * exp(-i E_a t), y = x * win * exp(+i mu t)."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    t = np.ascontiguousarray(times, dtype=np.float64)
+    E = np.ascontiguousarray(E_cols, dtype=np.float64)
+    w = None if win is None else np.ascontiguousarray(win, dtype=np.float64)
+    m = E.shape[0]
+    G = np.empty((m, m), dtype=np.complex128)
+    r = np.empty(m, dtype=np.complex128)
+    yy = ctypes.c_double(0.0)
+    _lib.check(_lib.load().mfft_lsq_normal_host(
+        x.ctypes.data, w.ctypes.data if w is not None else None, t.ctypes.data, x.shape[0], float(mu),
+        E.ctypes.data, int(m), G.ctypes.data, r.ctypes.data, ctypes.byref(yy)))
+    return G, r, yy.value
+
+
+def _solve_normal(G, r, yy, cols):
+    """Coefficients, clipped/normalised weights and residual norm of the fit that uses the
+    columns `cols`, from the normal equations.  None when that block is too ill-conditioned
+    for them (coincident lines): the caller then fits the explicit basis with lstsq, whose
+    minimum-norm answer is what the reference returns in that case."""
+    Gs = G[np.ix_(cols, cols)]
+    rs = r[cols]
+    try:
+        if np.linalg.cond(Gs) > 1e8:
+            return None
+        coef = np.linalg.solve(Gs, rs)
+    except np.linalg.LinAlgError:
+        return None
+    p = np.clip(coef.real, 0.0, None)
+    total = p.sum()
+    if total > 0:
+        p = p / total
+    res2 = yy - 2.0 * np.real(np.vdot(coef, rs)) + np.real(np.vdot(coef, Gs @ coef))
+    return coef, p, float(np.sqrt(max(res2, 0.0)))
+
+
 def _fit_weights(E, times, win, xw):
     """Least-squares amplitudes of sum_k c_k exp(-i E_k t) * win against xw, clipped
     to non-negative reals and normalised to sum 1 (when the sum is positive)."""
@@ -132,7 +199,7 @@ def fft_from_timeseries(
     n0 = len(f_t)
     nfft = int(max(1, pad_factor) * n0)
     S, smax, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), want_peaks=True)
-    omega = TWO_PI * fftfreq(nfft, d=dt)
+    omega = _omega_axis(nfft, dt)
     S_norm = S / (smax if smax > 0 else 1.0)
 
     span = times[-1] - times[0]
@@ -156,8 +223,15 @@ def fft_from_timeseries(
             break
     E_hat = -np.array([_refine_log_parabola(omega, S, i) for i in chosen])
 
-    win = _window_of(f_t, use_hann)
-    p, _, _ = _fit_weights(E_hat, times, win, f_t * win)
+    p = None
+    if 1 <= E_hat.size <= 16:
+        G, r, yy = _normal_equations(f_t, np.hanning(n0) if use_hann else None, times, E_hat)
+        fit = _solve_normal(G, r, yy, np.arange(E_hat.size))
+        if fit is not None:
+            p = fit[1]
+    if p is None:
+        win = _window_of(f_t, use_hann)
+        p, _, _ = _fit_weights(E_hat, times, win, f_t * win)
     if post_prune:
         keep = p > min_weight
         E_hat, p = E_hat[keep], p[keep]
@@ -245,13 +319,9 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
                                                    want_spectrum=False)
         if ssum > 0:
             mu = float((TWO_PI / (nfft * dt)) * centroid_bins / ssum)
-    xw = f_t * win
-    if demod and mu != 0.0:
-        xw = xw * np.exp(+1j * mu * times)
-
     S, _, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), mu=mu if demod else 0.0,
                                       t0=float(times[0]), want_peaks=True)
-    omega = TWO_PI * fftfreq(nfft, d=dt)
+    omega = _omega_axis(nfft, dt).copy()
     if cand.size == 0:
         return np.array([]), np.array([]), omega, S, mu
     by_height = cand[np.argsort(S[cand])][::-1]
@@ -268,11 +338,31 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
         return np.array([]), np.array([]), omega, S, mu
     mags = np.sort(np.unique(np.round(np.abs(omega[chosen]), 12)))[:n_peaks]
 
+    # Every fit of the 2^k sign search uses k of the 2k columns exp(-i(+-|omega|)t): reduce the
+    # Gram matrix of all 2k once on the device and read each fit off its sub-block.
+    k = len(mags)
+    demod_mu = mu if (demod and mu != 0.0) else 0.0
+    normal = None
+    if 2 * k <= 16:
+        normal = _normal_equations(f_t, win if use_hann else None, times,
+                                   np.concatenate((mags, -mags)), mu=demod_mu)
+    xw = None
     best_res, best_E, best_p = np.inf, None, None
-    for signs in itertools.product((-1.0, +1.0), repeat=len(mags)):
+    for signs in itertools.product((-1.0, +1.0), repeat=k):
         E_try = np.array([s * m for s, m in zip(signs, mags)])
-        p_try, basis, coef = _fit_weights(E_try, times, win, xw)
-        res = np.linalg.norm(basis @ coef - xw)
+        fit = None
+        if normal is not None:
+            cols = np.array([i if sg > 0 else k + i for i, sg in enumerate(signs)])
+            fit = _solve_normal(*normal, cols)
+        if fit is not None:
+            _, p_try, res = fit
+        else:
+            if xw is None:
+                xw = f_t * win
+                if demod_mu != 0.0:
+                    xw = xw * np.exp(+1j * mu * times)
+            p_try, basis, coef = _fit_weights(E_try, times, win, xw)
+            res = np.linalg.norm(basis @ coef - xw)
         if res < best_res:
             best_res, best_E, best_p = res, E_try, p_try
     E_phys = best_E - mu

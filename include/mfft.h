@@ -147,6 +147,22 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
                          double t0, double dt, double* h_stats, int64_t* h_idx, int64_t capacity,
                          int64_t* h_count);
 
+/* ---- weights of the spectral lines ----------------------------------------------
+ * Normal equations of the windowed least-squares fit both estimators end with
+ * (final2.py:174-175: lstsq(exp(-1j*outer(times, E)) * win[:, None], f_t*win);
+ * streamlit_app_combined.py:233-246: the same inside the 2^k sign search, against the
+ * demodulated xw).  With columns b_a[j] = win[j]*exp(-i*E[a]*times[j]), a < m <= 16, and
+ * target y[j] = x[j]*win[j]*exp(+i*mu*times[j]):
+ *     G[a][b] = sum_j conj(b_a[j])*b_b[j]     h_G: 2*m*m doubles, row-major, re/im interleaved
+ *     r[a]    = sum_j conj(b_a[j])*y[j]       h_r: 2*m doubles
+ *     yy      = sum_j |y[j]|^2                *h_yy
+ * so that the least-squares coefficients solve G c = r and the residual norm is
+ * sqrt(yy - 2 Re(c^H r) + c^H G c).  The sign search evaluates every +-|omega| column once
+ * (m = 2k) and reads each of its 2^k fits off sub-blocks of G.  h_x: n complex128 samples,
+ * h_win: n doubles or NULL (all ones), h_times: n doubles.  Synchronous. */
+int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_times, int64_t n,
+                         double mu, const double* h_E, int m, double* h_G, double* h_r, double* h_yy);
+
 /* ---- input generator -----------------------------------------------------------
  * Return amplitude of a small Hermitian block on a time grid,
  *     f[j] = sum_k vrow[k] * ( exp(-i * w[k] * t_j / hbar) * c0[k] ),   k < nk <= 32
