@@ -90,6 +90,37 @@ template <typename T> __device__ __forceinline__ void st_stream(T* p, T v)
 #endif
 }
 
+// Buffer-resource accesses for the runtime prologue / epilogue: the hardware range check
+// (byte offset = voffset + soffset against num_records) returns zero for loads beyond the
+// extent and drops stores beyond it, which IS zero padding, truncation and the inactive-slot
+// guard, with no index clamps, no predicates and one lane-dependent offset register.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kBufWord3 = 0x00020000u;      // raw buffer, 32-bit data format
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes)
+{
+    // the base is wave-uniform by construction (callers pass one signal per wave or more);
+    // say so, or the compiler wraps every access in a waterfall loop
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), (int)kBufWord3);
+}
+template <typename V> __device__ __forceinline__ V buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <typename V> __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, V v)
+{
+    if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 template <int R0, int R1, int R2, int R3, bool SPLIT16 = (MFFT_TW16_SPLIT != 0)> struct Radices {
     static constexpr int r[4] = {R0, R1, R2, R3};
     static constexpr bool split16 = SPLIT16;   // radix-16 passes keep six twiddle generators (see tw_rows)
@@ -345,32 +376,55 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                     v[e].y *= w;
                 }
             }
-        } else {
-            // Runtime prologue.  Every load is issued unconditionally at a clamped index and the
-            // options are uniform branches around whole 16-load loops, so the loads of one signal
-            // stay in flight together (a per-element branch would serialise them).
+        } else if constexpr (TX >= 64) {
+            // Runtime prologue, signals owned by whole waves: range-checked buffer loads.
+            // (The general variants take dense signals only; segmented layouts that V_SEG does
+            // not serve are staged through a dense buffer by the plan.)
             const int64_t bl = active ? b : a.batch - 1;
-            const int64_t base = bl * a.in_stride;
+            const uint32_t tt = (uint32_t)t;
+            if (a.real_in) {
+                const auto rs = make_rsrc(reinterpret_cast<const T*>(a.in) + bl * a.in_stride, (uint32_t)a.n_in * sizeof(T));
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = C{buf_ld<T>(rs, tt * sizeof(T), TX * e * sizeof(T)), 0};
+            } else {
+                const auto rs = make_rsrc(reinterpret_cast<const C*>(a.in) + bl * a.in_stride, (uint32_t)a.n_in * sizeof(C));
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = buf_ld<C>(rs, tt * sizeof(C), TX * e * sizeof(C));
+            }
+            if (a.conj_in) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
+            }
+            if (a.win) {
+                const auto rw = make_rsrc(a.win, (uint32_t)a.n_in * sizeof(T));
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    const T w = buf_ld<T>(rw, tt * sizeof(T), TX * e * sizeof(T));
+                    v[e].x *= w; v[e].y *= w;
+                }
+            }
+            if (a.pre) {
+                const auto rp = make_rsrc(a.pre, (uint32_t)a.n_in * sizeof(C));
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], buf_ld<C>(rp, tt * sizeof(C), TX * e * sizeof(C)));
+            }
+        } else {
+            // Runtime prologue, several signals per wave.  Every load is issued unconditionally at
+            // a clamped index and the options are uniform branches around whole loops, so the loads
+            // of one signal stay in flight together (a per-element branch would serialise them).
+            const int64_t bl = active ? b : a.batch - 1;
             const int last = a.n_in - 1;
             int jj[P];
 #pragma unroll
             for (int e = 0; e < P; ++e) { const int j = t + TX * e; jj[e] = j < last ? j : last; }
-            int64_t at[P];
-            if (a.in_seg > 0) {
-                const uint32_t seg = (uint32_t)a.in_seg;
-#pragma unroll
-                for (int e = 0; e < P; ++e)
-                    at[e] = base + (int64_t)((uint32_t)jj[e] / seg) * a.in_seg_stride + (int64_t)((uint32_t)jj[e] % seg);
-            } else {
-#pragma unroll
-                for (int e = 0; e < P; ++e) at[e] = base + jj[e];
-            }
             if (a.real_in) {
+                const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + bl * a.in_stride;
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = C{reinterpret_cast<const T*>(a.in)[at[e]], 0};
+                for (int e = 0; e < P; ++e) v[e] = C{src[jj[e]], 0};
             } else {
+                const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = reinterpret_cast<const C*>(a.in)[at[e]];
+                for (int e = 0; e < P; ++e) v[e] = src[jj[e]];
             }
             if (a.conj_in) {
 #pragma unroll
@@ -415,10 +469,17 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
             T s[P];
             if constexpr (GENERAL) {
                 if (a.post) {                  // |.|^2 ignores conj_out
+                    if constexpr (TX >= 64) {
+                        const auto rp = make_rsrc(a.post, (uint32_t)a.n_out * sizeof(C));
 #pragma unroll
-                    for (int e = 0; e < P; ++e) {
-                        const int k = t + TX * e;
-                        v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
+                        for (int e = 0; e < P; ++e)
+                            v[e] = cmul(v[e], buf_ld<C>(rp, (uint32_t)t * sizeof(C), TX * e * sizeof(C)));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            const int k = t + TX * e;
+                            v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
+                        }
                     }
                 }
             }
@@ -427,20 +488,16 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                 const T re = v[e].x * a.scale, im = v[e].y * a.scale;
                 s[e] = re * re + im * im;
             }
-            if (active) {
+            if constexpr (GENERAL && TX >= 64) {
+                // an inactive slot gets an empty extent: every store is dropped by the range check
+                const auto ro = make_rsrc(dst, active ? (uint32_t)a.n_out * sizeof(T) : 0u);
+#pragma unroll
+                for (int e = 0; e < P; ++e) buf_st<T>(ro, (uint32_t)t * sizeof(T), TX * e * sizeof(T), s[e]);
+            } else if (active) {
                 if constexpr (GENERAL) {
-                    if (a.out_seg > 0) {
-                        const uint32_t seg = (uint32_t)a.out_seg;
 #pragma unroll
-                        for (int e = 0; e < P; ++e) {
-                            const uint32_t k = (uint32_t)(t + TX * e);
-                            if ((int)k < a.n_out) dst[(int64_t)(k / seg) * a.out_seg_stride + (k % seg)] = s[e];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < P; ++e) {
-                            if (t + TX * e < a.n_out) dst[t + TX * e] = s[e];
-                        }
+                    for (int e = 0; e < P; ++e) {
+                        if (t + TX * e < a.n_out) dst[t + TX * e] = s[e];
                     }
                 } else {
 #pragma unroll
@@ -486,27 +543,29 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
                     for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
                 }
                 if (a.post) {
+                    if constexpr (TX >= 64) {
+                        const auto rp = make_rsrc(a.post, (uint32_t)a.n_out * sizeof(C));
 #pragma unroll
-                    for (int e = 0; e < P; ++e) {
-                        const int k = t + TX * e;
-                        v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
-                    }
-                }
-            }
-            if (active) {
-                if constexpr (GENERAL) {
-                    if (a.out_seg > 0) {
-                        const uint32_t seg = (uint32_t)a.out_seg;
-#pragma unroll
-                        for (int e = 0; e < P; ++e) {
-                            const uint32_t k = (uint32_t)(t + TX * e);
-                            if ((int)k < a.n_out) dst[(int64_t)(k / seg) * a.out_seg_stride + (k % seg)] = v[e];
-                        }
+                        for (int e = 0; e < P; ++e)
+                            v[e] = cmul(v[e], buf_ld<C>(rp, (uint32_t)t * sizeof(C), TX * e * sizeof(C)));
                     } else {
 #pragma unroll
                         for (int e = 0; e < P; ++e) {
-                            if (t + TX * e < a.n_out) dst[t + TX * e] = v[e];
+                            const int k = t + TX * e;
+                            v[e] = cmul(v[e], a.post[k < a.n_out ? k : a.n_out - 1]);
                         }
+                    }
+                }
+            }
+            if constexpr (GENERAL && TX >= 64) {
+                const auto ro = make_rsrc(dst, active ? (uint32_t)a.n_out * sizeof(C) : 0u);
+#pragma unroll
+                for (int e = 0; e < P; ++e) buf_st<C>(ro, (uint32_t)t * sizeof(C), TX * e * sizeof(C), v[e]);
+            } else if (active) {
+                if constexpr (GENERAL) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
+                        if (t + TX * e < a.n_out) dst[t + TX * e] = v[e];
                     }
                 } else if constexpr (VAR == V_SEG) {
                     const int q = a.out_lseg - LOG2TX;

@@ -166,6 +166,22 @@ __global__ void transpose_kernel(const cx<T>* in, cx<T>* out, int64_t rows, int6
     }
 }
 
+// dense[b][j] <-> seg[b*batch_stride + (j/seg)*seg_stride + j%seg] for `count` elements per signal of
+// type E (to_dense = gather, else scatter): stages the rare combinations of a segmented layout
+// with a runtime prologue / epilogue, which the LDS-resident general variants do not address
+template <typename E>
+__global__ void seg_copy_kernel(const E* src, E* dst, int64_t batch, int64_t count, int64_t batch_stride,
+                                int64_t seg, int64_t seg_stride, int to_dense)
+{
+    const int64_t total = batch * count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / count, j = i - b * count;
+        const int64_t at = b * batch_stride + seg_index(j, seg, seg_stride);
+        if (to_dense) dst[i] = src[at];
+        else dst[at] = src[i];
+    }
+}
+
 // out[b][a][:] = in[a][b][:] for an (A, B, W) array of complex elements: one row of W
 // contiguous elements per loop trip, copied 16 bytes per lane where W allows
 template <typename T>
@@ -415,6 +431,8 @@ struct Pow2Engine {
     void* d_tw = nullptr;               // single-kernel twiddles
     std::vector<GlobalPass> passes;     // tiled decomposition
     void* work[2] = {nullptr, nullptr};
+    void* stage_in = nullptr;           // dense copies around a general single-kernel transform whose
+    void* stage_out = nullptr;          // caller layout is segmented (allocated on first use)
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
@@ -557,9 +575,9 @@ void Pow2Engine::release()
             if (q) (void)hipFree(q);
     for (void* q : work)
         if (q) (void)hipFree(q);
-    for (void* q : {d_fs_lo, d_fs_hi})
+    for (void* q : {d_fs_lo, d_fs_hi, stage_in, stage_out})
         if (q) (void)hipFree(q);
-    d_fs_lo = d_fs_hi = nullptr;
+    d_fs_lo = d_fs_hi = stage_in = stage_out = nullptr;
     d_tw = nullptr; work[0] = work[1] = nullptr; passes.clear();
 }
 
@@ -597,8 +615,37 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.out_lseg = io.out_seg ? ilog2(io.out_seg) : 30;
         }
         else variant = io.power ? V_GEN_POWER : V_GEN_CPLX;
-        if constexpr (sizeof(T) == 4) return launch_lds_c64(log2n, variant, a, 0, s);
-        else return launch_lds_c128(log2n, variant, a, 0, s);
+        const bool general = variant == V_GEN_POWER || variant == V_GEN_CPLX;
+        const bool stage_i = general && io.in_seg > 0, stage_o = general && io.out_seg > 0;
+        const size_t in_esz = io.real_in ? sizeof(T) : sizeof(cx<T>), out_esz = io.power ? sizeof(T) : sizeof(cx<T>);
+        const auto seg_copy = [&](const void* src, void* dst, size_t esz, int64_t count, int64_t bstride, int64_t sg,
+                                  int64_t sgs, int to_dense) -> int {
+            const int64_t total = batch * count;
+            int64_t blocks = (total + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            if (blocks < 1) return MFFT_OK;
+            if (esz == 4) hipLaunchKernelGGL(seg_copy_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, batch, count, bstride, sg, sgs, to_dense);
+            else if (esz == 8) hipLaunchKernelGGL(seg_copy_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)src, (double*)dst, batch, count, bstride, sg, sgs, to_dense);
+            else hipLaunchKernelGGL(seg_copy_kernel<double2>, dim3((unsigned)blocks), dim3(256), 0, s, (const double2*)src, (double2*)dst, batch, count, bstride, sg, sgs, to_dense);
+            MFFT_HIP(hipGetLastError());
+            return MFFT_OK;
+        };
+        if (stage_i) {
+            if (!stage_in) MFFT_HIP(hipMalloc(&stage_in, (size_t)batch * (size_t)io.n_in * in_esz));
+            const int rc = seg_copy(io.in, stage_in, in_esz, io.n_in, io.in_stride, io.in_seg, io.in_seg_stride, 1);
+            if (rc) return rc;
+            a.in = stage_in; a.in_stride = io.n_in; a.in_seg = a.in_seg_stride = 0;
+        }
+        if (stage_o) {
+            if (!stage_out) MFFT_HIP(hipMalloc(&stage_out, (size_t)batch * (size_t)io.n_out * out_esz));
+            a.out = stage_out; a.out_stride = io.n_out; a.out_seg = a.out_seg_stride = 0;
+        }
+        int rc;
+        if constexpr (sizeof(T) == 4) rc = launch_lds_c64(log2n, variant, a, 0, s);
+        else rc = launch_lds_c128(log2n, variant, a, 0, s);
+        if (rc) return rc;
+        if (stage_o) return seg_copy(stage_out, io.out, out_esz, io.n_out, io.out_stride, io.out_seg, io.out_seg_stride, 0);
+        return MFFT_OK;
     }
     const int np = (int)passes.size();
     const void* src = io.in;

@@ -123,3 +123,44 @@ def test_argument_errors(fa):
     with fa.Plan(16) as p:
         with pytest.raises(ValueError):
             p.exec_host(np.zeros(8, np.complex64))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_layouts_through_every_route(fa, dtype):
+    """Segmented / strided device layouts: the fast segmented variant (power-of-two segments of at
+    least n/16 elements), the staged route (segments combined with a window, zero padding or a
+    chirp-z length) and the tile passes' own segmented load / store."""
+    import torch
+    import dist_helpers as dh
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    tdt = torch.complex64 if dtype == 0 else torch.complex128
+    cases = [
+        # n, n_in, batch, flags, in_layout, out_layout
+        (1024, 1024, 5, 0, (256, 256, 5 * 256), (128, 128, 5 * 128)),       # fast segmented variant
+        (16384 >> dtype, 16384 >> dtype, 3, 0, None, (2048, 2048, 3 * 2048)),
+        (4096, 4096, 2, 0, (8192, 0, 0), (5000, 0, 0)),                     # strided batches only
+        (1024, 1024, 5, fa.HANN, (256, 256, 5 * 256), (32, 32, 5 * 32)),    # window + segments: staged
+        (2048, 1500, 3, 0, (500, 500, 3 * 500), (64, 64, 3 * 64)),          # zero padding + segments
+        (256, 256, 9, 0, (8, 8, 9 * 8), (4, 4, 9 * 4)),                     # segments below n/16
+        (1000, 1000, 4, 0, (250, 250, 4 * 250), (100, 100, 4 * 100)),       # chirp-z length
+        (1 << 16, 1 << 16, 2, 0, (1 << 14, 1 << 14, 2 << 14), (1 << 13, 1 << 13, 2 << 13)),   # tile passes
+    ]
+    for n, n_in, batch, flags, lin, lout in cases:
+        idx_in = dh.layout_index(n_in, batch, lin, n_in)
+        idx_out = dh.layout_index(n, batch, lout, n)
+        x = _rand((batch, n_in), n + n_in + dtype, cdt)
+        buf_in = np.zeros(int(idx_in.max()) + 1, dtype=cdt)
+        buf_in[idx_in] = x
+        d_in = torch.from_numpy(buf_in).cuda()
+        d_out = torch.full((int(idx_out.max()) + 1,), complex(7.0, -7.0), dtype=tdt, device="cuda")
+        with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags, in_layout=lin, out_layout=lout) as p:
+            p.exec(d_in, d_out)
+            torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        xw = x * np.hanning(n_in) if flags & fa.HANN else x
+        ref = np.fft.fft(xw.astype(np.complex128), n=n, axis=-1)
+        tol = (3e-5 if n == 1000 else TOL[0]) if dtype == 0 else TOL[1]
+        assert rel_l2(got[idx_out], ref) < tol, (n, n_in, flags, lin, lout)
+        untouched = np.ones(got.shape[0], bool)
+        untouched[idx_out.ravel()] = False
+        assert np.all(got[untouched] == complex(7.0, -7.0)), "stored outside the layout"
