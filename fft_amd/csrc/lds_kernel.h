@@ -53,11 +53,19 @@ namespace mfft {
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2 };
 
+// Waves per SIMD the register allocator must leave room for (1 = no constraint).  The 8192-point
+// complex64 kernel (512 threads, 68 KiB of LDS) fits two workgroups per CU only at <= 128 VGPRs;
+// holding the plain variants there is worth +9..14 % (3.7 -> 4.05..4.3 TB/s); every other size and the
+// general variants (which then spill) measured slower when capped.
+template <typename T, int N, int VAR> constexpr int min_waves_per_eu()
+{
 #if MFFT_WAVES_PER_EU > 0
-#define MFFT_LAUNCH_BOUNDS(B) __launch_bounds__(B, MFFT_WAVES_PER_EU)
+    return MFFT_WAVES_PER_EU;
 #else
-#define MFFT_LAUNCH_BOUNDS(B) __launch_bounds__(B)
+    return (sizeof(T) == 4 && N == 8192 && (VAR == V_PLAIN || VAR == V_SEG)) ? 4 : 1;
 #endif
+}
+#define MFFT_LAUNCH_BOUNDS(B, T, N, VAR) __launch_bounds__(B, (min_waves_per_eu<T, N, VAR>()))
 
 // Streaming accesses: each input element is read once and each output written once.
 template <typename T> struct nt_vec { using type = T __attribute__((ext_vector_type(2))); };
@@ -294,7 +302,7 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 }
 
 template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
-__global__ void MFFT_LAUNCH_BOUNDS(BLOCK) fft_lds_kernel(const KArgs<T> a)
+__global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
 {
     using C = cx<T>;
     constexpr int N = RD::n;
