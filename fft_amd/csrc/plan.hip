@@ -135,6 +135,45 @@ __global__ void premul_kernel(cx<T>* pre, const T* win, const cx<T>* extra, int 
     pre[j] = cx<T>{(T)re, (T)im};
 }
 
+// chirp[j] = exp(-i*pi*j^2/n), j < n: j^2 is reduced mod 2n in integers (j < 2^31, so j^2 fits 64
+// bits), then to the nearest quarter turn, and the remaining angle |x| <= 1/4 (in units of pi) goes
+// through sincospi -- the phase error stays at the 1e-16 level for every j, as the long-double host
+// tables have it, at a fraction of their cost (the apps' largest length, 1.28e8 points: 12 s of host
+// sinl/cosl).
+template <typename T>
+__global__ void chirp_kernel(cx<T>* chirp, int64_t n)
+{
+    const uint64_t N = 2 * (uint64_t)n;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = ((uint64_t)j * (uint64_t)j) % N;
+        const uint64_t k4 = 4 * k;
+        const uint64_t q = (k4 + N / 2) / N;                          // nearest quarter turn
+        const int64_t rem = (int64_t)k4 - (int64_t)(q * N);           // |rem| <= N/2
+        double sa, ca;
+        sincospi((double)rem / (double)(2 * N), &sa, &ca);            // angle = 2*pi*rem/(4N)
+        double c, sn;
+        switch (q & 3) {
+        case 0: c = ca; sn = sa; break;
+        case 1: c = -sa; sn = ca; break;
+        case 2: c = -ca; sn = -sa; break;
+        default: c = sa; sn = -ca; break;
+        }
+        chirp[j] = cx<T>{(T)c, (T)(-sn)};
+    }
+}
+
+// Bluestein filter b[d] = conj(chirp[|d|]) for -n_in < d < n, wrapped into m points, zero elsewhere
+template <typename T>
+__global__ void chirp_filter_kernel(const cx<T>* chirp, cx<T>* b, int64_t n, int64_t n_in, int64_t m)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        cx<T> v{0, 0};
+        if (i < n) v = cx<T>{chirp[i].x, -chirp[i].y};
+        else if (m - i < n_in) v = cx<T>{chirp[m - i].x, -chirp[m - i].y};
+        b[i] = v;
+    }
+}
+
 template <typename T>
 __global__ void normalize_kernel(const T* in, T* out, int64_t count, const double* d_max)
 {
@@ -778,24 +817,30 @@ template <typename T> static int launch_premul(Plan* p, double mu, double t0, do
 
 template <typename T> static int build_chirpz(Plan* p)
 {
-    // chirp c[j] = exp(-i pi j^2 / n) with j^2 reduced mod 2n exactly
+    // chirp c[j] = exp(-i pi j^2 / n) and the wrapped filter, both generated on the device
     const int64_t n = p->n, m = p->m;
-    std::vector<long double> cr((size_t)n), ci((size_t)n);
-    for (int64_t j = 0; j < n; ++j) {
-        const int64_t jj = (int64_t)(((unsigned __int128)j * (unsigned __int128)j) % (unsigned __int128)(2 * n));
-        unit_root(jj, 2 * n, &cr[(size_t)j], &ci[(size_t)j]);
+    if (n >= (int64_t(1) << 31)) { set_error("chirp-z lengths are limited to 2^31 - 1"); return MFFT_E_UNSUPPORTED; }
+    MFFT_HIP(hipMalloc(&p->d_chirp, (size_t)n * sizeof(cx<T>)));
+    {
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(chirp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, nullptr,
+                           static_cast<cx<T>*>(p->d_chirp), n);
+        MFFT_HIP(hipGetLastError());
     }
-    int rc = upload_complex<T>(cr, ci, &p->d_chirp);
-    if (rc) return rc;
-    // filter b[d] = conj(c[|d|]) for -n_in < d < n, wrapped into m points
-    std::vector<cx<T>> hb((size_t)m, cx<T>{0, 0});
-    for (int64_t d = 0; d < n; ++d) hb[(size_t)d] = cx<T>{(T)cr[(size_t)d], (T)(-ci[(size_t)d])};
-    for (int64_t d = 1; d < p->n_in; ++d) hb[(size_t)(m - d)] = cx<T>{(T)cr[(size_t)d], (T)(-ci[(size_t)d])};
     void* d_b = nullptr;
     MFFT_HIP(hipMalloc(&d_b, (size_t)m * sizeof(cx<T>)));
-    hipError_t e = hipMemcpy(d_b, hb.data(), (size_t)m * sizeof(cx<T>), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
-    MFFT_HIP(hipMalloc(&p->d_filt, (size_t)m * sizeof(cx<T>)));
+    {
+        int64_t blocks = (m + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(chirp_filter_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, nullptr,
+                           static_cast<const cx<T>*>(p->d_chirp), static_cast<cx<T>*>(d_b), n, p->n_in, m);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(e, "chirp_filter_kernel", __FILE__, __LINE__); }
+    }
+    int rc;
+    hipError_t e = hipMalloc(&p->d_filt, (size_t)m * sizeof(cx<T>));
+    if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     // one-signal engine for the filter transform; conj_out stores conj(FFT(b)), the form the
     // first stage multiplies by
     Pow2Engine one;

@@ -109,3 +109,31 @@ def test_cfg4_2d_16384_c64():
             assert worst < 1e-5, worst
     finally:
         ops.close()
+
+
+def test_largest_app_length():
+    """The reference's widgets allow tmax/dt up to N0 = 2 000 001 samples and pad 64
+    (final2.py:534-535, :599): Nfft = 128 000 064, a chirp-z length.  Plan, run, and compare
+    sampled bins of the power spectrum with the direct sum (exact integer phase reduction)."""
+    import time
+    import fft_amd as fa
+    n0, pad, dt = 2000001, 64, 0.01
+    n = n0 * pad
+    rng = np.random.default_rng(7)
+    times = np.arange(n0) * dt
+    x = (0.7 * np.exp(-1j * 0.37 * times) + 0.3 * np.exp(+1j * 2.5 * times)
+         + 1e-3 * (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)))
+    t0 = time.perf_counter()
+    with fa.Plan(n, n_in=n0, dtype=fa.C128, flags=fa.HANN | fa.POWER | fa.STATS) as p:
+        assert time.perf_counter() - t0 < 10.0, "plan tables are generated on the device"
+        S, st = p.exec_host(x, scale=dt)
+    assert S.shape == (n,) and S.dtype == np.float64
+    k_peak = int(np.argmax(S))
+    assert k_peak == n - round(0.37 * dt * n / (2 * np.pi))           # E = -omega convention: bin of -0.37
+    assert st[0, 0] == S[k_peak]
+    xw = x * np.hanning(n0)
+    j = np.arange(n0, dtype=np.int64)
+    for k in (0, 1, k_peak - 1, k_peak, k_peak + 1, n // 2, n - 1, 50937212, round(2.5 * dt * n / (2 * np.pi))):
+        ph = ((j * int(k)) % n).astype(np.float64) / n                 # exact: j*k < 2^63
+        want = np.abs(dt * np.sum(xw * np.exp(-2j * np.pi * ph))) ** 2
+        assert abs(S[k] - want) <= 1e-11 * S[k_peak] + 1e-9 * want, (k, S[k], want)
