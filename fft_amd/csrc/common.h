@@ -108,7 +108,7 @@ template <typename T> struct TArgs;
 enum { kTileMinLog2G = 4, kTileMaxLog2G = 9 };
 int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s);
 int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s);
-int tile_log2c_c64(int log2g);    // log2 of the columns per tile for this radix
-int tile_log2c_c128(int log2g);
+int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class
+int tile_log2c_c128(int log2g, int narrow);
 
 }  // namespace mfft

@@ -474,6 +474,7 @@ struct Pow2Engine {
     void* stage_out = nullptr;          // caller layout is segmented (allocated on first use)
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
+    int narrow = 0;                     // tile width class (TileCols)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
     int fs_lb = 0;
@@ -486,15 +487,15 @@ struct Pow2Engine {
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
 };
 
-static int tile_log2c(int dtype, int log2g)
+static int tile_log2c(int dtype, int log2g, int narrow)
 {
-    return dtype == MFFT_C64 ? tile_log2c_c64(log2g) : tile_log2c_c128(log2g);
+    return dtype == MFFT_C64 ? tile_log2c_c64(log2g, narrow) : tile_log2c_c128(log2g, narrow);
 }
 
 // How a length above one LDS residency is split into global passes (log2 of each radix, first
 // pass first).  Fewest passes first; within that the radices are balanced, larger ones first.
 // MFFT_SPLIT="8,8,8" overrides the choice (tuning aid; must multiply to the length).
-static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_inner = 0)
+static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_inner = 0, int narrow = 0)
 {
     out->clear();
     if (const char* env = getenv("MFFT_SPLIT")) {
@@ -519,10 +520,10 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
         // later passes need NS >= columns per tile; the tile count L/C must be >= 1
         if (log2_inner) {
             // column-batched: a tile is C adjacent columns of one butterfly
-            if (log2_inner < tile_log2c(dtype, g)) { set_error("fewer columns than a tile is wide"); return MFFT_E_UNSUPPORTED; }
-        } else if (log2n - g < tile_log2c(dtype, g)) { set_error("tile wider than the pass"); return MFFT_E_UNSUPPORTED; }
+            if (log2_inner < tile_log2c(dtype, g, narrow)) { set_error("fewer columns than a tile is wide"); return MFFT_E_UNSUPPORTED; }
+        } else if (log2n - g < tile_log2c(dtype, g, narrow)) { set_error("tile wider than the pass"); return MFFT_E_UNSUPPORTED; }
     }
-    if (!log2_inner && out->size() >= 2 && (*out)[0] < tile_log2c(dtype, (*out)[1])) { set_error("first radix below tile width"); return MFFT_E_UNSUPPORTED; }
+    if (!log2_inner && out->size() >= 2 && (*out)[0] < tile_log2c(dtype, (*out)[1], narrow)) { set_error("first radix below tile width"); return MFFT_E_UNSUPPORTED; }
     return MFFT_OK;
 }
 
@@ -544,7 +545,12 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     single = false;
     std::vector<int> split;
     const int log2_inner = ilog2(inner);
-    int rc0 = choose_split(log2n, dtype, &split, log2_inner);
+    int rc0 = choose_split(log2n, dtype, &split, log2_inner, 0);
+    narrow = 0;
+    if (rc0 && inner > 1) {             // fewer columns than a wide tile: the narrow width
+        narrow = 1;
+        rc0 = choose_split(log2n, dtype, &split, log2_inner, 1);
+    }
     if (rc0) return rc0;
     const int npass = (int)split.size();
     int64_t ns = inner;                 // counts elements: the columns are an innermost, finished "pass"
@@ -706,7 +712,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.NS = gp.ns;
         a.log2_ns = ilog2(gp.ns);
         a.log2_w = ilog2(inner);
-        a.log2_tiles = log2nn - gp.log2g - tile_log2c(dtype, gp.log2g);
+        a.log2_tiles = log2nn - gp.log2g - tile_log2c(dtype, gp.log2g, narrow);
+        a.narrow = narrow;
         a.batch = batch;
         a.lb = gp.lb;
         a.nt = tile_nt;

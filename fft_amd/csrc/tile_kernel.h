@@ -87,6 +87,7 @@ template <typename T> struct TArgs {
     int log2_ns;          // NS = 1 << log2_ns
     int log2_tiles;       // tiles per signal = (L / C) = 1 << log2_tiles
     int real_in, conj_in, conj_out;
+    int narrow;           // 1: the narrow tile width (see TileCols)
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     T scale;
 };
@@ -97,12 +98,17 @@ template <typename T> struct TArgs {
 enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN = 3, TM_LAST_GEN = 4,
                 TM_LAST_POWER = 5, TM_LAST_TWID = 6 };
 
-// Columns per tile: 256-byte rows where LDS allows (32 complex64 / 16 complex128 up to 256-point
-// columns), 128-byte rows for the 512-point tile (the largest: a 1024-point tile would need 1024
-// threads at <= 128 VGPRs for complex64, which spills, or more than 160 KiB for complex128).  Measured on MI355X, a G x run
-// strided copy moves 4.4-5.0 TB/s at 128-B runs and 5.0-5.3 TB/s at 256-B runs.
-template <typename T, int LOG2G> struct TileCols {
-    static constexpr int LOG2C = (sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0);
+// Columns per tile.  Wide (default): 512-byte rows where LDS allows -- 64 complex64 columns up to
+// 128-point tiles, 32 at 256 points, 16 at 512; 32 complex128 columns up to 256 points, 16 at 512.
+// Narrow (column-batched arrays with fewer columns than a wide tile): 256-byte rows, 128 at 512
+// points.  Measured on MI355X, a G x run strided copy moves 4.4-5.0 TB/s at 128-B runs, 5.0-5.3
+// TB/s at 256-B runs and ~5.5 TB/s from 512 B; on the transforms wide tiles are worth +5..8 %
+// (complex64, 2^19..2^22 points) and +2..13 % (complex128, every length), while 64 complex64
+// columns at 256 points (one 1024-thread workgroup per CU) lose 6-9 %.
+template <typename T, int LOG2G, bool NARROW> struct TileCols {
+    static constexpr int WIDE = sizeof(T) == 4 ? (LOG2G <= 7 ? 6 : (LOG2G == 8 ? 5 : 4)) : (LOG2G <= 8 ? 5 : 4);
+    static constexpr int SLIM = (sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0);
+    static constexpr int LOG2C = NARROW ? SLIM : WIDE;
 };
 
 template <int LOG2G> struct TileCfg {
@@ -427,7 +433,18 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
 template <typename T, int LOG2G>
 int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
 {
-    constexpr int LC = TileCols<T, LOG2G>::LOG2C;
+    constexpr int LC = TileCols<T, LOG2G, false>::LOG2C;
+    constexpr int LN = TileCols<T, LOG2G, true>::LOG2C;
+    if (a.narrow && LN != LC) {
+        // only the modes a column-batched transform uses exist at the narrow width
+        switch (mode) {
+        case TM_MID: return launch_tile_one<T, LOG2G, LN, TM_MID>(a, s);
+        case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LN, TM_LAST_PLAIN>(a, s);
+        case TM_LAST_TWID: return launch_tile_one<T, LOG2G, LN, TM_LAST_TWID>(a, s);
+        }
+        set_error("tile mode not built at the narrow width");
+        return MFFT_E_UNSUPPORTED;
+    }
     switch (mode) {
     case TM_MID: return launch_tile_one<T, LOG2G, LC, TM_MID>(a, s);
     case TM_FIRST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_PLAIN>(a, s);
@@ -456,15 +473,15 @@ int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
     return MFFT_E_UNSUPPORTED;
 }
 
-template <typename T> int tile_log2c_for(int log2g)
+template <typename T> int tile_log2c_for(int log2g, bool narrow)
 {
     switch (log2g) {
-    case 4: return TileCols<T, 4>::LOG2C;
-    case 5: return TileCols<T, 5>::LOG2C;
-    case 6: return TileCols<T, 6>::LOG2C;
-    case 7: return TileCols<T, 7>::LOG2C;
-    case 8: return TileCols<T, 8>::LOG2C;
-    case 9: return TileCols<T, 9>::LOG2C;
+    case 4: return narrow ? TileCols<T, 4, true>::LOG2C : TileCols<T, 4, false>::LOG2C;
+    case 5: return narrow ? TileCols<T, 5, true>::LOG2C : TileCols<T, 5, false>::LOG2C;
+    case 6: return narrow ? TileCols<T, 6, true>::LOG2C : TileCols<T, 6, false>::LOG2C;
+    case 7: return narrow ? TileCols<T, 7, true>::LOG2C : TileCols<T, 7, false>::LOG2C;
+    case 8: return narrow ? TileCols<T, 8, true>::LOG2C : TileCols<T, 8, false>::LOG2C;
+    case 9: return narrow ? TileCols<T, 9, true>::LOG2C : TileCols<T, 9, false>::LOG2C;
     }
     return 0;
 }
