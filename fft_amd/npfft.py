@@ -21,11 +21,12 @@ _cache: "OrderedDict[tuple, Plan]" = OrderedDict()
 _cache_lock = threading.Lock()
 
 
-def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int) -> Plan:
+def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int, device=None) -> Plan:
     """Plans own device tables and workspace, so they are kept and reused.  The
     cache is shared by all threads (Streamlit runs one script thread per session);
-    a plan serialises its own executions."""
-    key = (int(n), int(n_in), int(batch), int(dtype), int(flags))
+    a plan serialises its own executions.  A plan belongs to the HIP device that is current
+    when it is built; `device` only keys the cache for callers that switch devices."""
+    key = (int(n), int(n_in), int(batch), int(dtype), int(flags), device)
     with _cache_lock:
         plan = _cache.get(key)
         if plan is not None:
@@ -63,10 +64,54 @@ def engine_dtype(a: np.ndarray):
     return _lib.C128, True
 
 
+def _fft_device(a, n, axis, norm):
+    """`fft` on a torch CUDA tensor: same semantics, the data never leaves the GPU (torch owns
+    the memory and the stream; the transform is libmfft's)."""
+    import torch
+    if a.dim() == 0:
+        raise ValueError("fft requires at least a 1-D array")
+    n_have = a.shape[axis]
+    n = n_have if n is None else int(n)
+    if n < 1:
+        raise ValueError(f"Invalid number of FFT data points ({n}) specified.")
+    if norm not in (None, "backward", "ortho", "forward"):
+        raise ValueError(f'Invalid norm value {norm}; should be "backward", "ortho" or "forward".')
+    if a.dtype in (torch.complex64, torch.float32, torch.float16):
+        dtype, rdt, cdt = _lib.C64, torch.float32, torch.complex64
+    else:
+        dtype, rdt, cdt = _lib.C128, torch.float64, torch.complex128
+    real_in = not a.is_complex()
+    x = a.movedim(axis, -1)
+    if n < n_have:
+        x = x[..., :n]
+    n_in = x.shape[-1]
+    lead = tuple(x.shape[:-1])
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    y = torch.empty(lead + (n,), dtype=cdt, device=a.device)
+    if batch == 0:
+        return y.movedim(-1, axis)
+    x = x.to(rdt if real_in else cdt).contiguous()
+    scale = {None: 1.0, "backward": 1.0, "ortho": 1.0 / np.sqrt(n), "forward": 1.0 / n}[norm]
+    with torch.cuda.device(a.device):
+        plan = cached_plan(n, n_in, batch, dtype, _lib.REAL_IN if real_in else 0, device=a.device.index)
+        with plan._lock:
+            plan.exec(x, y, scale=scale, stream=torch.cuda.current_stream().cuda_stream)
+    return y.movedim(-1, axis)
+
+
 def fft(a, n=None, axis=-1, norm=None, out=None):
-    """One-dimensional forward DFT along ``axis``, as ``numpy.fft.fft``."""
+    """One-dimensional forward DFT along ``axis``, as ``numpy.fft.fft``.  Array-likes go in and
+    come out as numpy arrays; a torch CUDA tensor is transformed in place on its device and a
+    CUDA tensor comes back (no PCIe traffic)."""
     if out is not None:
         raise NotImplementedError("the `out` argument is not supported")
+    if hasattr(a, "is_cuda") and hasattr(a, "data_ptr"):
+        if not a.is_cuda:
+            a = a.numpy()
+        else:
+            return _fft_device(a, n, axis, norm)
     a = np.asarray(a)
     if a.ndim == 0:
         raise ValueError("fft requires at least a 1-D array")

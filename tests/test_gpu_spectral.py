@@ -218,3 +218,23 @@ def test_local_maxima_scan(fa):
     assert set(idx[:100].tolist()) <= set(want.tolist())
     with pytest.raises(ValueError):
         _lib.check(lib.mfft_local_maxima(None, 8, _lib.C128, None, 8, None, None))
+
+
+def test_fft_on_device_tensors(fa):
+    """fft() on torch CUDA tensors: numpy semantics, result stays on the device."""
+    import torch
+    x = _rand((3, 5, 64), 1, np.complex128)
+    d = torch.from_numpy(x).cuda()
+    for axis in (-1, 0, 1):
+        y = fa.fft(d, axis=axis)
+        assert y.is_cuda and y.dtype == torch.complex128
+        assert rel_l2(y.cpu().numpy(), np.fft.fft(x, axis=axis)) < 1e-13
+    assert rel_l2(fa.fft(d, n=100).cpu().numpy(), np.fft.fft(x, n=100)) < 1e-12
+    assert rel_l2(fa.fft(d, n=16, norm="ortho").cpu().numpy(), np.fft.fft(x, n=16, norm="ortho")) < 1e-13
+    xr = torch.randn(4, 1000, device="cuda")
+    yr = fa.fft(xr)
+    assert yr.dtype == torch.complex64 and rel_l2(yr.cpu().numpy(), np.fft.fft(xr.cpu().numpy().astype(np.float64))) < 1e-5
+    big = torch.view_as_complex(torch.randn(4, 1 << 20, 2, device="cuda"))
+    assert rel_l2(fa.fft(big).cpu().numpy(), np.fft.fft(big.cpu().numpy().astype(np.complex128))) < 1e-5
+    assert fa.fft(torch.zeros(0, 8, device="cuda")).shape == (0, 8)
+    assert rel_l2(fa.fft(torch.from_numpy(x)), np.fft.fft(x)) < 1e-13        # CPU tensor: numpy path
