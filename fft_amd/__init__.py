@@ -11,11 +11,11 @@ Layers (bottom up):
 from . import _lib
 from .engine import Plan, ColumnPlan
 from ._lib import C64, C128, HANN, POWER, DEMOD, REAL_IN, STATS, INVERSE, MfftError, device_count
-from .npfft import fft, fftfreq, clear_plan_cache
+from .npfft import fft, fft2, fftfreq, clear_plan_cache
 from .spectral import (fft_from_timeseries, fft_extract_E_p, power_spectrum, return_amplitude,
                        return_amplitude_block_general, Heff_block_general)
 
 __all__ = ["Plan", "ColumnPlan", "C64", "C128", "HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE",
-           "MfftError", "device_count", "fft", "fftfreq", "clear_plan_cache",
+           "MfftError", "device_count", "fft", "fft2", "fftfreq", "clear_plan_cache",
            "fft_from_timeseries", "fft_extract_E_p", "power_spectrum", "return_amplitude",
            "return_amplitude_block_general", "Heff_block_general"]

@@ -14,7 +14,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .engine import Plan
+from .engine import ColumnPlan, Plan
 
 _CACHE_MAX = 24
 _cache: "OrderedDict[tuple, Plan]" = OrderedDict()
@@ -41,15 +41,57 @@ def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int, device=No
         _cache[key] = plan
         while len(_cache) > _CACHE_MAX:
             _, old = _cache.popitem(last=False)
-            old.destroy()
+            if old is not None:
+                old.destroy()
     return plan
+
+
+def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
+    """Column-batched plan for (batch, n, inner) arrays, or None when the tile passes do not
+    serve the shape (the caller then moves the axis last)."""
+    key = ("columns", int(n), int(inner), int(batch), int(dtype), device)
+    with _cache_lock:
+        if key in _cache:
+            _cache.move_to_end(key)
+            return _cache[key]
+    try:
+        plan = ColumnPlan(n, inner, batch=batch, dtype=dtype)
+    except _lib.MfftError:
+        plan = None
+    with _cache_lock:
+        other = _cache.get(key)
+        if other is not None:
+            if plan is not None:
+                plan.destroy()
+            return other
+        _cache[key] = plan
+        while len(_cache) > _CACHE_MAX:
+            _, old = _cache.popitem(last=False)
+            if old is not None:
+                old.destroy()
+    return plan
+
+
+def _column_shape(shape, axis, n):
+    """(batch, inner) when a transform of the full axis `axis` of a C-contiguous array of this
+    shape can run as a column-batched plan: a middle or leading axis, power-of-two extents."""
+    nd = len(shape)
+    ax = axis % nd
+    if ax == nd - 1 or n != shape[ax] or n < 16 or n & (n - 1):
+        return None
+    inner = int(np.prod(shape[ax + 1:]))
+    batch = int(np.prod(shape[:ax])) if ax else 1
+    if inner < 16 or inner & (inner - 1) or batch < 1:
+        return None
+    return batch, inner
 
 
 def clear_plan_cache():
     with _cache_lock:
         while _cache:
             _, p = _cache.popitem()
-            p.destroy()
+            if p is not None:
+                p.destroy()
 
 
 def engine_dtype(a: np.ndarray):
@@ -81,6 +123,19 @@ def _fft_device(a, n, axis, norm):
     else:
         dtype, rdt, cdt = _lib.C128, torch.float64, torch.complex128
     real_in = not a.is_complex()
+    cs = None if real_in else _column_shape(tuple(a.shape), axis, n)
+    if cs is not None and a.numel() > 0:
+        # a middle / leading axis: transform the strided columns where they lie (no transposes)
+        with torch.cuda.device(a.device):
+            plan = cached_column_plan(n, cs[1], cs[0], dtype, device=a.device.index)
+            if plan is not None:
+                x = a.to(cdt).contiguous()
+                y = torch.empty_like(x)
+                with plan._lock:
+                    plan.exec(x, y, stream=torch.cuda.current_stream().cuda_stream)
+                if norm in ("ortho", "forward"):
+                    y *= (1.0 / np.sqrt(n)) if norm == "ortho" else (1.0 / n)
+                return y
     x = a.movedim(axis, -1)
     if n < n_have:
         x = x[..., :n]
@@ -124,6 +179,14 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
     dtype, real_in = engine_dtype(a)
     rdt = np.float32 if dtype == _lib.C64 else np.float64
     cdt = np.complex64 if dtype == _lib.C64 else np.complex128
+    cs = None if real_in else _column_shape(a.shape, axis, n)
+    if cs is not None and a.size > 0:
+        plan = cached_column_plan(n, cs[1], cs[0], dtype)
+        if plan is not None:
+            y = plan.exec_host(np.ascontiguousarray(a, dtype=cdt)).reshape(a.shape)
+            if norm in ("ortho", "forward"):
+                y *= (1.0 / np.sqrt(n)) if norm == "ortho" else (1.0 / n)
+            return y
     x = np.moveaxis(a, axis, -1)
     if n < n_have:
         x = x[..., :n]                         # numpy crops when n is shorter than the axis
@@ -137,6 +200,25 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
     plan = cached_plan(n, n_in, batch, dtype, _lib.REAL_IN if real_in else 0)
     y = plan.exec_host(x, scale=scale)
     return np.moveaxis(y.reshape(lead + (n,)), -1, axis)
+
+
+def fft2(a, norm=None):
+    """Two-dimensional forward DFT over the last two axes, as ``numpy.fft.fft2(a)``: row
+    transforms, then the column transforms on the strided columns (no transpose pass when the
+    shape allows).  numpy arrays and torch CUDA tensors, like `fft`."""
+    if not (hasattr(a, "is_cuda") and hasattr(a, "data_ptr")):
+        a = np.asarray(a)
+        if a.ndim < 2:
+            raise ValueError("fft2 requires at least a 2-D array")
+        try:
+            import torch
+        except ImportError:
+            torch = None
+        if torch is not None and a.size > 0 and a.dtype.kind in "fc" and a.dtype.itemsize >= 4:
+            # one trip over the bus: both transforms run on the device copy
+            d = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            return fft(fft(d, axis=-1, norm=norm), axis=-2, norm=norm).cpu().numpy()
+    return fft(fft(a, axis=-1, norm=norm), axis=-2, norm=norm)
 
 
 def fftfreq(n, d=1.0):

@@ -238,3 +238,21 @@ def test_fft_on_device_tensors(fa):
     assert rel_l2(fa.fft(big).cpu().numpy(), np.fft.fft(big.cpu().numpy().astype(np.complex128))) < 1e-5
     assert fa.fft(torch.zeros(0, 8, device="cuda")).shape == (0, 8)
     assert rel_l2(fa.fft(torch.from_numpy(x)), np.fft.fft(x)) < 1e-13        # CPU tensor: numpy path
+
+
+def test_axis_transforms_and_fft2(fa):
+    """Leading / middle axes run column-batched where the shape allows; fft2 is rows then columns."""
+    import torch
+    for shape, dtype, tol in (((64, 256), np.complex128, 1e-13), ((3, 128, 64), np.complex64, 1e-5),
+                              ((2, 16, 4, 8), np.complex128, 1e-13), ((48, 32), np.complex128, 1e-12)):
+        x = _rand(shape, sum(shape), dtype)
+        for axis in range(len(shape)):
+            for norm in (None, "ortho"):
+                want = np.fft.fft(x.astype(np.complex128), axis=axis, norm=norm)
+                got = fa.fft(x, axis=axis, norm=norm)
+                assert got.dtype == dtype and rel_l2(got, want) < tol, (shape, axis, norm)
+                got_d = fa.fft(torch.from_numpy(x).cuda(), axis=axis, norm=norm)
+                assert rel_l2(got_d.cpu().numpy(), want) < tol, (shape, axis, norm)
+    a = _rand((512, 1024), 9, np.complex64)
+    assert rel_l2(fa.fft2(a), np.fft.fft2(a.astype(np.complex128))) < 1e-5
+    assert rel_l2(fa.fft2(torch.from_numpy(a).cuda()).cpu().numpy(), np.fft.fft2(a.astype(np.complex128))) < 1e-5
