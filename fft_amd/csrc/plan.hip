@@ -270,16 +270,17 @@ __global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_
 //   r[a]    = sum_j conj(b_a[j]) y[j]     (2*m doubles)
 //   yy      = sum_j |y[j]|^2              (1 double, accumulated by row 0)
 struct LsqArgs {
-    int m;
+    int m;            // all columns (rows of G): blockIdx.y
+    int c0, nc;       // this launch fills columns [c0, c0 + nc), nc <= 16
     double mu;
-    double E[16];
+    double E[64];
 };
 
 __global__ void __launch_bounds__(256) lsq_normal_kernel(const cx<double>* x, const double* win, const double* times,
                                                          int64_t n, LsqArgs a, double* out)
 {
     const int row = blockIdx.y;
-    const int m = a.m;
+    const int m = a.m, nc = a.nc;
     double gr[16], gi[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) { gr[b] = 0.0; gi[b] = 0.0; }
@@ -292,46 +293,50 @@ __global__ void __launch_bounds__(256) lsq_normal_kernel(const cx<double>* x, co
         const double ar = w * ca, ai = w * sa;
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            if (b < m) {
+            if (b < nc) {
                 double sb, cb;
-                sincos(a.E[b] * t, &sb, &cb);          // b_b = w (cb - i sb)
+                sincos(a.E[a.c0 + b] * t, &sb, &cb);   // b_b = w (cb - i sb)
                 const double br = w * cb, bi = -w * sb;
                 gr[b] += ar * br - ai * bi;
                 gi[b] += ar * bi + ai * br;
             }
         }
-        cx<double> y = x[j];
-        y.x *= w; y.y *= w;
-        if (a.mu != 0.0) {
-            double sm, cm;
-            sincos(a.mu * t, &sm, &cm);
-            y = cx<double>{y.x * cm - y.y * sm, y.x * sm + y.y * cm};
+        if (a.c0 == 0) {                               // right-hand side and target energy: first launch only
+            cx<double> y = x[j];
+            y.x *= w; y.y *= w;
+            if (a.mu != 0.0) {
+                double sm, cm;
+                sincos(a.mu * t, &sm, &cm);
+                y = cx<double>{y.x * cm - y.y * sm, y.x * sm + y.y * cm};
+            }
+            rr += ar * y.x - ai * y.y;
+            ri += ar * y.y + ai * y.x;
+            yy += y.x * y.x + y.y * y.y;
         }
-        rr += ar * y.x - ai * y.y;
-        ri += ar * y.y + ai * y.x;
-        yy += y.x * y.x + y.y * y.y;
     }
     // wave reduction, then one atomic per wave and value
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            if (b < m) { gr[b] += __shfl_xor(gr[b], o, 64); gi[b] += __shfl_xor(gi[b], o, 64); }
+            if (b < nc) { gr[b] += __shfl_xor(gr[b], o, 64); gi[b] += __shfl_xor(gi[b], o, 64); }
         }
         rr += __shfl_xor(rr, o, 64);
         ri += __shfl_xor(ri, o, 64);
         yy += __shfl_xor(yy, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        double* G = out + 2 * (size_t)row * m;
+        double* G = out + 2 * ((size_t)row * m + a.c0);
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            if (b < m) { atomicAdd(G + 2 * b, gr[b]); atomicAdd(G + 2 * b + 1, gi[b]); }
+            if (b < nc) { atomicAdd(G + 2 * b, gr[b]); atomicAdd(G + 2 * b + 1, gi[b]); }
         }
-        double* r = out + 2 * (size_t)m * m + 2 * row;
-        atomicAdd(r, rr);
-        atomicAdd(r + 1, ri);
-        if (row == 0) atomicAdd(out + 2 * (size_t)m * m + 2 * m, yy);
+        if (a.c0 == 0) {
+            double* r = out + 2 * (size_t)m * m + 2 * row;
+            atomicAdd(r, rr);
+            atomicAdd(r + 1, ri);
+            if (row == 0) atomicAdd(out + 2 * (size_t)m * m + 2 * m, yy);
+        }
     }
 }
 
@@ -1252,12 +1257,12 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
                          const double* h_E, int m, double* h_G, double* h_r, double* h_yy)
 {
     if (!h_x || !h_times || !h_E || !h_G || !h_r || !h_yy || n < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
-    if (m < 1 || m > 16) { set_error("1 <= m <= 16 columns"); return MFFT_E_INVALID; }
+    if (m < 1 || m > 64) { set_error("1 <= m <= 64 columns"); return MFFT_E_INVALID; }
     if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
     LsqArgs a;
     a.m = m;
     a.mu = mu;
-    for (int i = 0; i < 16; ++i) a.E[i] = i < m ? h_E[i] : 0.0;
+    for (int i = 0; i < 64; ++i) a.E[i] = i < m ? h_E[i] : 0.0;
     // one device block: x (2n) | times (n) | win (n) | results (2mm + 2m + 1)
     const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
     const size_t doubles = 4 * (size_t)n + nres;
@@ -1274,10 +1279,14 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
     if (e == hipSuccess) {
         int64_t blocks = (n + 255) / 256;
         if (blocks > 64) blocks = 64;
-        hipLaunchKernelGGL(lsq_normal_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, nullptr,
-                           reinterpret_cast<const cx<double>*>(d_x), h_win ? d_w : (const double*)nullptr, d_t, n, a,
-                           d_res);
-        e = hipGetLastError();
+        for (int c0 = 0; c0 < m && e == hipSuccess; c0 += 16) {      // 16 columns of G per launch
+            a.c0 = c0;
+            a.nc = m - c0 < 16 ? m - c0 : 16;
+            hipLaunchKernelGGL(lsq_normal_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, nullptr,
+                               reinterpret_cast<const cx<double>*>(d_x), h_win ? d_w : (const double*)nullptr, d_t, n,
+                               a, d_res);
+            e = hipGetLastError();
+        }
     }
     std::vector<double> res(nres);
     if (e == hipSuccess) e = hipMemcpy(res.data(), d_res, nres * sizeof(double), hipMemcpyDeviceToHost);

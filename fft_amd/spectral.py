@@ -135,35 +135,18 @@ def _normal_equations(x, win, times, E_cols, mu=0.0):
 
 def _solve_normal(G, r, yy, cols):
     """Coefficients, clipped/normalised weights and residual norm of the fit that uses the
-    columns `cols`, from the normal equations.  None when that block is too ill-conditioned
-    for them (coincident lines): the caller then fits the explicit basis with lstsq, whose
-    minimum-norm answer is what the reference returns in that case."""
+    columns `cols`, from the normal equations G c = r.  The k x k system is solved in the
+    minimum-norm least-squares sense, which is also what lstsq on the N0 x k basis returns when
+    columns coincide (c = B^+ y = (B^H B)^+ B^H y)."""
     Gs = G[np.ix_(cols, cols)]
     rs = r[cols]
-    try:
-        if np.linalg.cond(Gs) > 1e8:
-            return None
-        coef = np.linalg.solve(Gs, rs)
-    except np.linalg.LinAlgError:
-        return None
+    coef = np.linalg.lstsq(Gs, rs, rcond=1e-12)[0]
     p = np.clip(coef.real, 0.0, None)
     total = p.sum()
     if total > 0:
         p = p / total
     res2 = yy - 2.0 * np.real(np.vdot(coef, rs)) + np.real(np.vdot(coef, Gs @ coef))
     return coef, p, float(np.sqrt(max(res2, 0.0)))
-
-
-def _fit_weights(E, times, win, xw):
-    """Least-squares amplitudes of sum_k c_k exp(-i E_k t) * win against xw, clipped
-    to non-negative reals and normalised to sum 1 (when the sum is positive)."""
-    basis = np.exp(-1j * np.outer(times, np.asarray(E, float))) * np.asarray(win)[:, None]
-    coef, *_ = np.linalg.lstsq(basis, xw, rcond=None)
-    p = np.clip(coef.real, 0.0, None)
-    total = p.sum()
-    if total > 0:
-        p = p / total
-    return p, basis, coef
 
 
 # --------------------------------------------------------------------------- estimator A
@@ -223,15 +206,10 @@ def fft_from_timeseries(
             break
     E_hat = -np.array([_refine_log_parabola(omega, S, i) for i in chosen])
 
-    p = None
-    if 1 <= E_hat.size <= 16:
-        G, r, yy = _normal_equations(f_t, np.hanning(n0) if use_hann else None, times, E_hat)
-        fit = _solve_normal(G, r, yy, np.arange(E_hat.size))
-        if fit is not None:
-            p = fit[1]
-    if p is None:
-        win = _window_of(f_t, use_hann)
-        p, _, _ = _fit_weights(E_hat, times, win, f_t * win)
+    if E_hat.size > 64:
+        raise ValueError("at most 64 spectral lines can be fitted at once")
+    G, r, yy = _normal_equations(f_t, np.hanning(n0) if use_hann else None, times, E_hat)
+    _, p, _ = _solve_normal(G, r, yy, np.arange(E_hat.size))
     if post_prune:
         keep = p > min_weight
         E_hat, p = E_hat[keep], p[keep]
@@ -341,28 +319,16 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
     # Every fit of the 2^k sign search uses k of the 2k columns exp(-i(+-|omega|)t): reduce the
     # Gram matrix of all 2k once on the device and read each fit off its sub-block.
     k = len(mags)
+    if 2 * k > 64:
+        raise ValueError("at most 32 peaks can enter the sign search")
     demod_mu = mu if (demod and mu != 0.0) else 0.0
-    normal = None
-    if 2 * k <= 16:
-        normal = _normal_equations(f_t, win if use_hann else None, times,
-                                   np.concatenate((mags, -mags)), mu=demod_mu)
-    xw = None
+    G, r, yy = _normal_equations(f_t, win if use_hann else None, times, np.concatenate((mags, -mags)),
+                                 mu=demod_mu)
     best_res, best_E, best_p = np.inf, None, None
     for signs in itertools.product((-1.0, +1.0), repeat=k):
         E_try = np.array([s * m for s, m in zip(signs, mags)])
-        fit = None
-        if normal is not None:
-            cols = np.array([i if sg > 0 else k + i for i, sg in enumerate(signs)])
-            fit = _solve_normal(*normal, cols)
-        if fit is not None:
-            _, p_try, res = fit
-        else:
-            if xw is None:
-                xw = f_t * win
-                if demod_mu != 0.0:
-                    xw = xw * np.exp(+1j * mu * times)
-            p_try, basis, coef = _fit_weights(E_try, times, win, xw)
-            res = np.linalg.norm(basis @ coef - xw)
+        cols = np.array([i if sg > 0 else k + i for i, sg in enumerate(signs)])
+        _, p_try, res = _solve_normal(G, r, yy, cols)
         if res < best_res:
             best_res, best_E, best_p = res, E_try, p_try
     E_phys = best_E - mu

@@ -151,7 +151,7 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
  * Normal equations of the windowed least-squares fit both estimators end with
  * (final2.py:174-175: lstsq(exp(-1j*outer(times, E)) * win[:, None], f_t*win);
  * streamlit_app_combined.py:233-246: the same inside the 2^k sign search, against the
- * demodulated xw).  With columns b_a[j] = win[j]*exp(-i*E[a]*times[j]), a < m <= 16, and
+ * demodulated xw).  With columns b_a[j] = win[j]*exp(-i*E[a]*times[j]), a < m <= 64, and
  * target y[j] = x[j]*win[j]*exp(+i*mu*times[j]):
  *     G[a][b] = sum_j conj(b_a[j])*b_b[j]     h_G: 2*m*m doubles, row-major, re/im interleaved
  *     r[a]    = sum_j conj(b_a[j])*y[j]       h_r: 2*m doubles

@@ -256,3 +256,26 @@ def test_axis_transforms_and_fft2(fa):
     a = _rand((512, 1024), 9, np.complex64)
     assert rel_l2(fa.fft2(a), np.fft.fft2(a.astype(np.complex128))) < 1e-5
     assert rel_l2(fa.fft2(torch.from_numpy(a).cuda()).cpu().numpy(), np.fft.fft2(a.astype(np.complex128))) < 1e-5
+
+
+def test_normal_equations_on_device(fa):
+    """Gram matrix, right-hand side and target energy of the windowed line fit (final2.py:174-175,
+    streamlit_app_combined.py:233-246) against numpy, including more than 16 columns (two launches)
+    and the demodulated target."""
+    from fft_amd.spectral import _normal_equations
+    rng = np.random.default_rng(12)
+    for n0, m, mu, hann in ((8001, 3, 0.0, True), (1501, 6, -0.81, True), (700, 20, 0.3, False), (50, 1, 0.0, True)):
+        t = np.sort(rng.random(n0)) * 40.0 if m == 20 else np.arange(n0) * 0.01
+        E = rng.uniform(-300, 300, m)
+        x = rng.standard_normal(n0) + 1j * rng.standard_normal(n0)
+        win = np.hanning(n0) if hann else None
+        G, r, yy = _normal_equations(x, win, t, E, mu=mu)
+        w = win if hann else np.ones(n0)
+        B = np.exp(-1j * np.outer(t, E)) * w[:, None]
+        y = x * w * np.exp(1j * mu * t)
+        scale = np.linalg.norm(B.conj().T @ B)
+        assert np.linalg.norm(G - B.conj().T @ B) < 1e-12 * scale
+        assert np.linalg.norm(r - B.conj().T @ y) < 1e-12 * np.linalg.norm(B) * np.linalg.norm(y)
+        assert abs(yy - np.vdot(y, y).real) < 1e-12 * yy
+    with pytest.raises(ValueError):
+        _normal_equations(x, None, t, np.zeros(65))

@@ -89,7 +89,7 @@ def test_local_maxima_tie_rule():
 
 
 def test_refine_and_fit_match_oracle():
-    from fft_amd.spectral import _refine_log_parabola, _fit_weights
+    from fft_amd.spectral import _refine_log_parabola, _solve_normal
     rng = np.random.default_rng(3)
     y = rng.random(50) + 0.1
     x = np.linspace(-3, 3, 50)
@@ -101,9 +101,23 @@ def test_refine_and_fit_match_oracle():
     E = np.array([-1.0, 0.4, 2.2]); p = np.array([0.5, 0.3, 0.2])
     win = np.hanning(len(t))
     xw = (p[None, :] * np.exp(-1j * np.outer(t, E))).sum(axis=1) * win
-    got, basis, coef = _fit_weights(E, t, win, xw)
+    # the k x k normal-equation solve against lstsq on the explicit N0 x k basis
+    basis = np.exp(-1j * np.outer(t, E)) * win[:, None]
+    G, r, yy = basis.conj().T @ basis, basis.conj().T @ xw, float(np.vdot(xw, xw).real)
+    coef, got, res = _solve_normal(G, r, yy, np.arange(3))
     np.testing.assert_allclose(got, p, atol=1e-12)
-    assert np.linalg.norm(basis @ coef - xw) < 1e-12
+    assert res < 1e-7 and np.linalg.norm(basis @ coef - xw) < 1e-10
+    noisy = xw + 0.05 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))
+    want = np.linalg.lstsq(basis, noisy, rcond=None)[0]
+    coef, _, res = _solve_normal(G, basis.conj().T @ noisy, float(np.vdot(noisy, noisy).real), np.arange(3))
+    np.testing.assert_allclose(coef, want, atol=1e-12)
+    assert abs(res - np.linalg.norm(basis @ want - noisy)) < 1e-9
+    # coincident columns: the minimum-norm solution, as lstsq on the basis gives
+    E2 = np.array([0.4, 0.4, 2.2])
+    b2 = np.exp(-1j * np.outer(t, E2)) * win[:, None]
+    want = np.linalg.lstsq(b2, noisy, rcond=None)[0]
+    coef, _, _ = _solve_normal(b2.conj().T @ b2, b2.conj().T @ noisy, float(np.vdot(noisy, noisy).real), np.arange(3))
+    np.testing.assert_allclose(coef, want, atol=1e-9)
 
 
 def test_heff_block_matches_oracle():
