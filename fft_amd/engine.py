@@ -111,8 +111,8 @@ class Plan:
     def exec_host_peaks(self, x: np.ndarray, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0,
                         dt: float = 1.0, capacity: int = 65536):
         """exec_host for a one-signal POWER|STATS plan plus the device-side scan for interior
-        local maxima.  Returns (S, stats, idx) with idx ascending, or idx = None when more than
-        `capacity` maxima exist (the caller then scans S itself)."""
+        local maxima.  Returns (S, stats, idx) with idx ascending; when more than `capacity`
+        maxima exist idx is their total count instead (an int: call again with that capacity)."""
         if self._h is None:
             raise ValueError("plan already destroyed")
         if not (self.flags & _lib.POWER and self.flags & _lib.STATS) or self.batch != 1:
@@ -129,7 +129,7 @@ class Plan:
                 self._h, x.ctypes.data, out.ctypes.data, float(scale), float(mu), float(t0), float(dt),
                 stats.ctypes.data, idx.ctypes.data, int(capacity), ctypes.byref(count)))
         if count.value > capacity:
-            return out, stats, None
+            return out, stats, int(count.value)
         return out, stats, np.sort(idx[:count.value])
 
     # -- lifetime ---------------------------------------------------------------

@@ -79,9 +79,11 @@ def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0
     plan = cached_plan(nfft, x.shape[0], 1, _lib.C128, flags)
     xin = np.ascontiguousarray(x, dtype=np.float64 if real_in else np.complex128)
     if want_peaks:
-        S, stats, idx = plan.exec_host_peaks(xin, scale=dt, mu=mu, t0=t0, dt=dt)
-        if idx is None:                       # more maxima than the device buffer holds
-            idx = _local_maxima(S)
+        # a zero-padded spectrum has about one local maximum per side lobe, i.e. ~n_in of them
+        S, stats, idx = plan.exec_host_peaks(xin, scale=dt, mu=mu, t0=t0, dt=dt,
+                                             capacity=max(65536, 2 * x.shape[0]))
+        if not isinstance(idx, np.ndarray):   # more than that (noise-like spectrum): rerun with room for all
+            S, stats, idx = plan.exec_host_peaks(xin, scale=dt, mu=mu, t0=t0, dt=dt, capacity=int(idx))
         return S, float(stats[0, 0]), float(stats[0, 1]), float(stats[0, 2]), idx
     if want_spectrum:
         S, stats = plan.exec_host(xin, scale=dt, mu=mu, t0=t0, dt=dt)
@@ -91,12 +93,6 @@ def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0
 
 
 # --------------------------------------------------------------------------- host tail
-
-def _local_maxima(S):
-    """Indices i in [1, len-2] with S[i-1] < S[i] >= S[i+1] (left strict, right weak)."""
-    mid = S[1:-1]
-    return np.flatnonzero((mid > S[:-2]) & (mid >= S[2:])) + 1
-
 
 def _refine_log_parabola(x, y, i):
     """Vertex of the parabola through (x, log y) at i-1, i, i+1; x[i] at the edges or

@@ -279,3 +279,17 @@ def test_normal_equations_on_device(fa):
         assert abs(yy - np.vdot(y, y).real) < 1e-12 * yy
     with pytest.raises(ValueError):
         _normal_equations(x, None, t, np.zeros(65))
+
+
+def test_peak_buffer_overflow_reruns_on_device(fa):
+    """A noise-like spectrum has far more local maxima than samples: the scan is repeated with
+    room for all of them, still on the device."""
+    rng = np.random.default_rng(21)
+    n0, pad = 300, 512
+    x = rng.standard_normal(n0) + 1j * rng.standard_normal(n0)
+    S, smax, ssum, cen, idx = fa.power_spectrum(x, n0 * pad, 0.01, use_hann=False, want_peaks=True)
+    want = np.flatnonzero((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:])) + 1
+    assert np.array_equal(idx, want)
+    plan_S, stats, few = fa.npfft.cached_plan(n0 * pad, n0, 1, fa.C128, fa.POWER | fa.STATS).exec_host_peaks(
+        x, scale=0.01, capacity=8)
+    assert isinstance(few, int) and few == want.size

@@ -80,14 +80,6 @@ def test_fftfreq_matches_numpy(n, d):
     assert np.array_equal(fft_amd.fftfreq(n, d), np.fft.fftfreq(n, d))
 
 
-def test_local_maxima_tie_rule():
-    from fft_amd.spectral import _local_maxima
-    S = np.array([0.0, 1.0, 1.0, 0.5, 2.0, 2.0, 2.0, 0.1, 3.0])
-    # left strict, right weak: of a plateau only its first sample qualifies; the last sample never does
-    ref = np.where((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:]))[0] + 1
-    assert list(_local_maxima(S)) == list(ref) == [1, 4]
-
-
 def test_refine_and_fit_match_oracle():
     from fft_amd.spectral import _refine_log_parabola, _solve_normal
     rng = np.random.default_rng(3)
