@@ -159,7 +159,7 @@ def test_layouts_through_every_route(fa, dtype):
         got = d_out.cpu().numpy()
         xw = x * np.hanning(n_in) if flags & fa.HANN else x
         ref = np.fft.fft(xw.astype(np.complex128), n=n, axis=-1)
-        tol = (3e-5 if n == 1000 else TOL[0]) if dtype == 0 else TOL[1]
+        tol = TOL[dtype]
         assert rel_l2(got[idx_out], ref) < tol, (n, n_in, flags, lin, lout)
         untouched = np.ones(got.shape[0], bool)
         untouched[idx_out.ravel()] = False
