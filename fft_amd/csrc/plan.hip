@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <new>
 
 #include "common.h"
@@ -431,6 +434,7 @@ template <typename T> struct Io {
     int real_in = 0, conj_in = 0, conj_out = 0;
     T scale = 1;
     bool power = false;
+    int64_t batch = 0;     // > 0: transform only this many signals (a slab of the plan's batch)
 };
 
 template <typename T>
@@ -633,12 +637,13 @@ void Pow2Engine::release()
 
 template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
 {
+    const int64_t nb = io.batch > 0 ? io.batch : batch;
     if (single) {
         KArgs<T> a{};
         a.in = io.in; a.out = io.out;
         a.tw = static_cast<const cx<T>*>(d_tw);
         a.win = io.win; a.pre = io.pre; a.post = io.post; a.stats = io.stats;
-        a.batch = batch;
+        a.batch = nb;
         a.in_stride = io.in_stride; a.out_stride = io.out_stride;
         a.in_seg = io.in_seg; a.in_seg_stride = io.in_seg_stride;
         a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
@@ -670,13 +675,13 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         const size_t in_esz = io.real_in ? sizeof(T) : sizeof(cx<T>), out_esz = io.power ? sizeof(T) : sizeof(cx<T>);
         const auto seg_copy = [&](const void* src, void* dst, size_t esz, int64_t count, int64_t bstride, int64_t sg,
                                   int64_t sgs, int to_dense) -> int {
-            const int64_t total = batch * count;
+            const int64_t total = nb * count;
             int64_t blocks = (total + 255) / 256;
             if (blocks > 8192) blocks = 8192;
             if (blocks < 1) return MFFT_OK;
-            if (esz == 4) hipLaunchKernelGGL(seg_copy_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, batch, count, bstride, sg, sgs, to_dense);
-            else if (esz == 8) hipLaunchKernelGGL(seg_copy_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)src, (double*)dst, batch, count, bstride, sg, sgs, to_dense);
-            else hipLaunchKernelGGL(seg_copy_kernel<double2>, dim3((unsigned)blocks), dim3(256), 0, s, (const double2*)src, (double2*)dst, batch, count, bstride, sg, sgs, to_dense);
+            if (esz == 4) hipLaunchKernelGGL(seg_copy_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, nb, count, bstride, sg, sgs, to_dense);
+            else if (esz == 8) hipLaunchKernelGGL(seg_copy_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)src, (double*)dst, nb, count, bstride, sg, sgs, to_dense);
+            else hipLaunchKernelGGL(seg_copy_kernel<double2>, dim3((unsigned)blocks), dim3(256), 0, s, (const double2*)src, (double2*)dst, nb, count, bstride, sg, sgs, to_dense);
             MFFT_HIP(hipGetLastError());
             return MFFT_OK;
         };
@@ -719,7 +724,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.log2_w = ilog2(inner);
         a.log2_tiles = log2nn - gp.log2g - tile_log2c(dtype, gp.log2g, narrow);
         a.narrow = narrow;
-        a.batch = batch;
+        a.batch = nb;
         a.lb = gp.lb;
         a.nt = tile_nt;
         a.scale = 1;
@@ -784,6 +789,12 @@ struct Plan {
     void* d_in = nullptr;
     void* d_out = nullptr;
     double* d_stats = nullptr;
+    // pipelined staging for large mfft_exec_host transfers (built on first use)
+    void* pin_in[2] = {nullptr, nullptr};
+    void* pin_out[2] = {nullptr, nullptr};
+    hipStream_t s_run = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    int64_t pipe_slab = 0;        // signals per slab
     int64_t* d_peaks = nullptr;   // [0] = count, [1..] = candidate indices (mfft_exec_host_peaks)
     int64_t peak_cap = 0;
     int64_t workspace = 0;
@@ -813,6 +824,12 @@ static void plan_free(Plan* p)
     for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
                     (void*)p->d_peaks})
         if (q) (void)hipFree(q);
+    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1]})
+        if (q) (void)hipHostFree(q);
+    for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1]})
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {p->s_run, p->s_out})
+        if (st) (void)hipStreamDestroy(st);
     if (have_prev) (void)hipSetDevice(prev);
     delete p;
 }
@@ -931,14 +948,17 @@ static int plan_build(Plan* p)
 
 template <typename T>
 static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
-                      double* d_stats, hipStream_t s)
+                      double* d_stats, hipStream_t s, int64_t slab = 0, bool tables = true)
 {
+    // slab > 0: d_in / d_out / d_stats point at a run of `slab` signals of the batch (the pipelined
+    // host path); `tables` = rebuild the per-call premultiplier (first slab only)
+    const int64_t nb = slab > 0 ? slab : p->batch;
     const bool demod = (p->flags & MFFT_DEMOD) != 0;
     const bool power = (p->flags & MFFT_POWER) != 0;
     const bool inverse = (p->flags & MFFT_INVERSE) != 0;
     double* stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
-    if (stats) MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)p->batch, s));
-    if (demod) {
+    if (stats) MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)nb, s));
+    if (demod && tables) {
         const int rc = launch_premul<T>(p, mu, t0, dt, 1, s);
         if (rc) return rc;
     }
@@ -946,9 +966,9 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     const cx<T>* pre = static_cast<const cx<T>*>(p->d_pre);
 
     if (p->kind == Plan::ONE_POINT) {
-        const int64_t blocks = (p->batch + 255) / 256;
+        const int64_t blocks = (nb + 255) / 256;
         if (p->lout.batch_stride > 1) { set_error("1-point plans take dense output only"); return MFFT_E_UNSUPPORTED; }
-        hipLaunchKernelGGL(n1_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, d_in, d_out, p->batch,
+        hipLaunchKernelGGL(n1_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, d_in, d_out, nb,
                            p->lin.batch_stride ? p->lin.batch_stride : p->n_in,
                            (p->flags & MFFT_REAL_IN) ? 1 : 0, demod ? (const T*)nullptr : win,
                            demod ? pre : (const cx<T>*)nullptr, (T)scale, inverse ? 1 : 0, power ? 1 : 0, stats);
@@ -961,6 +981,7 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
         io.in = d_in; io.out = d_out;
         io.in_stride = io.out_stride = p->n * p->inner;
         io.n_in = io.n_out = p->n;
+        io.batch = slab;
         return p->eng.exec<T>(io, s);
     }
     if (p->kind == Plan::POW2) {
@@ -978,6 +999,7 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
         io.conj_in = inverse; io.conj_out = inverse;
         io.scale = (T)scale;
         io.power = power;
+        io.batch = slab;
         return p->eng.exec<T>(io, s);
     }
     // chirp-z: X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j]
@@ -992,6 +1014,7 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     a.n_in = p->n_in; a.n_out = p->m;
     a.real_in = (p->flags & MFFT_REAL_IN) ? 1 : 0;
     a.conj_out = 1;
+    a.batch = slab;
     int rc = p->eng.exec<T>(a, s);
     if (rc) return rc;
     Io<T> b;                                        // stage 2: conj(FFT_m(.)) / m * c[k], first n bins
@@ -1005,14 +1028,138 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     b.conj_out = 1;
     b.scale = (T)(scale / (double)p->m);
     b.power = power;
+    b.batch = slab;
     return p->eng.exec<T>(b, s);
 }
 
 static int plan_exec(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
-                     double* d_stats, hipStream_t s)
+                     double* d_stats, hipStream_t s, int64_t slab = 0, bool tables = true)
 {
-    return p->dtype == MFFT_C64 ? exec_typed<float>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s)
-                                : exec_typed<double>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
+    return p->dtype == MFFT_C64 ? exec_typed<float>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables)
+                                : exec_typed<double>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
+}
+
+// ---------------------------------------------------------------------------
+// Host side of mfft_exec_host for large batches.  One thread moves pageable memory at 3-5 GB/s
+// (page faults on fresh numpy arrays included) while the bus takes 57 GB/s from pinned memory, so
+// the batch is cut into slabs that a few threads copy through two pinned buffers per direction
+// while the previous slab is on the bus and in the kernels.
+// ---------------------------------------------------------------------------
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool* pool = new CopyPool;      // never destroyed: its threads outlive main()
+        return *pool;
+    }
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        const int parts = bytes < (size_t(1) << 20) ? 1 : nthreads_;
+        if (parts <= 1) { memcpy(dst, src, bytes); return; }
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_.wait(lk, [&] { return pending_ == 0; });        // one job at a time
+        dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes;
+        next_ = 0; parts_ = parts; pending_ = parts;
+        ++generation_;
+        work_.notify_all();
+        idle_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+private:
+    CopyPool()
+    {
+        int n = 8;                                  // measured on the GPU box: 3 -> 6 -> 12 threads = 29 -> 25 -> 22 ms per GiB moved
+        if (const char* env = getenv("MFFT_COPY_THREADS")) n = atoi(env);
+        nthreads_ = n < 1 ? 1 : (n > 32 ? 32 : n);
+        for (int i = 0; i < nthreads_; ++i) std::thread([this] { loop(); }).detach();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            work_.wait(lk, [&] { return generation_ != seen && next_ < parts_; });
+            while (next_ < parts_) {
+                const int part = next_++;
+                const size_t per = (bytes_ + (size_t)parts_ - 1) / (size_t)parts_;
+                const size_t lo = (size_t)part * per, hi = lo + per > bytes_ ? bytes_ : lo + per;
+                char* d = dst_; const char* sr = src_;
+                lk.unlock();
+                if (lo < hi) memcpy(d + lo, sr + lo, hi - lo);
+                lk.lock();
+                if (--pending_ == 0) idle_.notify_all();
+            }
+            seen = generation_;
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable work_, idle_;
+    char* dst_ = nullptr; const char* src_ = nullptr;
+    size_t bytes_ = 0;
+    int next_ = 0, parts_ = 0, pending_ = 0, nthreads_ = 1;
+    uint64_t generation_ = 0;
+};
+
+static int pipe_prepare(Plan* p, size_t in_row, size_t out_row)
+{
+    if (p->pipe_slab > 0) return MFFT_OK;
+    const size_t target = size_t(16) << 20;                    // bytes per slab and direction
+    const size_t row = in_row > out_row ? in_row : out_row;
+    int64_t slab = (int64_t)(target / row);
+    if (slab < 1) slab = 1;
+    for (int q = 0; q < 2; ++q) {
+        MFFT_HIP(hipHostMalloc(&p->pin_in[q], (size_t)slab * in_row, hipHostMallocDefault));
+        MFFT_HIP(hipHostMalloc(&p->pin_out[q], (size_t)slab * out_row, hipHostMallocDefault));
+        MFFT_HIP(hipEventCreateWithFlags(&p->ev_in[q], hipEventDisableTiming));
+        MFFT_HIP(hipEventCreateWithFlags(&p->ev_run[q], hipEventDisableTiming));
+        MFFT_HIP(hipEventCreateWithFlags(&p->ev_out[q], hipEventDisableTiming));
+    }
+    MFFT_HIP(hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking));
+    MFFT_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    p->pipe_slab = slab;
+    return MFFT_OK;
+}
+
+// h_in -> (threads) pinned -> H2D -> kernels -> D2H -> pinned -> (threads) h_out, two slabs in flight
+static int exec_host_pipelined(Plan* p, const char* h_in, char* h_out, size_t in_row, size_t out_row, double scale,
+                               double mu, double t0, double dt)
+{
+    int rc = pipe_prepare(p, in_row, out_row);
+    if (rc) return rc;
+    CopyPool& pool = CopyPool::get();
+    const int64_t slab = p->pipe_slab, batch = p->batch;
+    const int64_t nslab = (batch + slab - 1) / slab;
+    char* d_in = static_cast<char*>(p->d_in);
+    char* d_out = static_cast<char*>(p->d_out);
+    for (int64_t k = 0; k < nslab; ++k) {
+        const int q = (int)(k & 1);
+        const int64_t b0 = k * slab, cnt = batch - b0 < slab ? batch - b0 : slab;
+        if (k >= 2) MFFT_HIP(hipEventSynchronize(p->ev_in[q]));             // pin_in[q] has left for the device
+        pool.copy(p->pin_in[q], h_in + (size_t)b0 * in_row, (size_t)cnt * in_row);
+        MFFT_HIP(hipMemcpyAsync(d_in + (size_t)b0 * in_row, p->pin_in[q], (size_t)cnt * in_row, hipMemcpyHostToDevice, p->s_run));
+        MFFT_HIP(hipEventRecord(p->ev_in[q], p->s_run));
+        rc = plan_exec(p, d_in + (size_t)b0 * in_row, d_out + (size_t)b0 * out_row, scale, mu, t0, dt,
+                       p->d_stats ? p->d_stats + 3 * b0 : nullptr, p->s_run, cnt, k == 0);
+        if (rc) { (void)hipStreamSynchronize(p->s_run); (void)hipStreamSynchronize(p->s_out); return rc; }
+        if (h_out) {
+            MFFT_HIP(hipEventRecord(p->ev_run[q], p->s_run));
+            MFFT_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[q], 0));
+            MFFT_HIP(hipMemcpyAsync(p->pin_out[q], d_out + (size_t)b0 * out_row, (size_t)cnt * out_row, hipMemcpyDeviceToHost, p->s_out));
+            MFFT_HIP(hipEventRecord(p->ev_out[q], p->s_out));
+            if (k >= 1) {                                                    // drain the previous slab meanwhile
+                MFFT_HIP(hipEventSynchronize(p->ev_out[q ^ 1]));
+                pool.copy(h_out + (size_t)(b0 - slab) * out_row, p->pin_out[q ^ 1], (size_t)slab * out_row);
+            }
+        }
+    }
+    if (h_out) {
+        const int q = (int)((nslab - 1) & 1);
+        const int64_t b0 = (nslab - 1) * slab;
+        MFFT_HIP(hipEventSynchronize(p->ev_out[q]));
+        pool.copy(h_out + (size_t)b0 * out_row, p->pin_out[q], (size_t)(batch - b0) * out_row);
+    }
+    MFFT_HIP(hipStreamSynchronize(p->s_run));
+    return MFFT_OK;
 }
 
 // RAII: make the plan's device current for the duration of a call
@@ -1186,10 +1333,19 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     if (!p->d_out) MFFT_HIP(hipMalloc(&p->d_out, out_bytes));
     if ((p->flags & MFFT_STATS) && !p->d_stats)
         MFFT_HIP(hipMalloc((void**)&p->d_stats, sizeof(double) * 3 * (size_t)p->batch));
-    MFFT_HIP(hipMemcpy(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice));
-    const int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
-    if (rc != MFFT_OK) return rc;
-    if (h_out) MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
+    const size_t in_row = in_bytes / (size_t)p->batch, out_row = out_bytes / (size_t)p->batch;
+    const bool pipelined = p->kind != Plan::COLUMNS && p->batch >= 4 && in_bytes + (h_out ? out_bytes : 0) >= (size_t(48) << 20) &&
+                           in_row <= (size_t(64) << 20) && !getenv("MFFT_NO_PIPELINE");
+    if (pipelined) {
+        const int rc = exec_host_pipelined(p, static_cast<const char*>(h_in), static_cast<char*>(h_out), in_row, out_row,
+                                           scale, mu, t0, dt);
+        if (rc != MFFT_OK) return rc;
+    } else {
+        MFFT_HIP(hipMemcpy(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice));
+        const int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
+        if (rc != MFFT_OK) return rc;
+        if (h_out) MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
+    }
     if (p->flags & MFFT_STATS)
         MFFT_HIP(hipMemcpy(h_stats, p->d_stats, sizeof(double) * 3 * (size_t)p->batch, hipMemcpyDeviceToHost));
     return MFFT_OK;

@@ -129,3 +129,36 @@ def test_column_batched_plans(fa, dtype):
     for n, inner in ((8, 64), (48, 64), (64, 8), (64, 48)):
         with pytest.raises(fa.MfftError):
             fa.ColumnPlan(n, inner, dtype=dtype)
+
+
+def test_pipelined_host_path(fa, monkeypatch):
+    """Large host batches go through pinned slabs (copy threads, two slabs in flight): results must
+    equal the single-copy path bit for bit, ragged last slab and per-signal statistics included."""
+    rng = np.random.default_rng(31)
+    cases = [
+        (1024, 1024, 8192 + 77, 0, 0),                                   # single kernel, complex64
+        (1024, 700, 9000, 0, fa.HANN | fa.POWER | fa.STATS),             # zero padding + statistics
+        (1000, 1000, 9000, 0, 0),                                        # chirp-z
+        (1 << 16, 1 << 16, 131, 0, fa.REAL_IN | fa.POWER),               # tile passes, real input
+        (4096, 4096, 1100, 1, fa.DEMOD | fa.HANN),                       # complex128, demodulation table
+    ]
+    for n, n_in, batch, dtype, flags in cases:
+        rdt, cdt = (np.float32, np.complex64) if dtype == 0 else (np.float64, np.complex128)
+        if flags & fa.REAL_IN:
+            x = rng.standard_normal((batch, n_in)).astype(rdt)
+        else:
+            x = (rng.standard_normal((batch, n_in), dtype=np.float32)
+                 + 1j * rng.standard_normal((batch, n_in), dtype=np.float32)).astype(cdt)
+        with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags) as p:
+            monkeypatch.setenv("MFFT_NO_PIPELINE", "1")
+            ref = p.exec_host(x, scale=0.5, mu=0.3, t0=0.1, dt=0.01)
+            monkeypatch.delenv("MFFT_NO_PIPELINE")
+            for _ in range(2):                                           # second call reuses the pinned slabs
+                got = p.exec_host(x, scale=0.5, mu=0.3, t0=0.1, dt=0.01)
+                if flags & fa.STATS:
+                    assert np.array_equal(got[0], ref[0]) and np.allclose(got[1], ref[1], rtol=1e-12)
+                else:
+                    assert np.array_equal(got, ref), (n, n_in, batch, flags)
+            if flags & fa.STATS:
+                st = p.exec_host(x, scale=0.5, stats_only=True)
+                assert np.allclose(st, ref[1], rtol=1e-12)
