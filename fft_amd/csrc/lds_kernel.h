@@ -38,6 +38,9 @@
 #ifndef MFFT_NT
 #define MFFT_NT 1            // 1 = non-temporal global loads/stores in the fast variants (+10 % on the 1024-point batch)
 #endif
+#ifndef MFFT_FAST_BUF
+#define MFFT_FAST_BUF 0      // tuning aid: 1 = buffer-resource accesses (scalar offsets) in the plain / hann+power variants
+#endif
 #ifndef MFFT_TW16_SPLIT
 #define MFFT_TW16_SPLIT 1    // radix-16 passes keep w^1,w^2,w^3,w^4,w^8,w^12 and form the other nine by one multiply
 #endif
@@ -116,17 +119,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), (int)kBufWord3);
 }
-template <typename V> __device__ __forceinline__ V buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+// AUX: cache-policy bits of the instruction (0 = default, 2 = streaming / non-temporal)
+template <typename V, int AUX = 0> __device__ __forceinline__ V buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
-    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-    else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-    else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+    else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+    else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
 }
-template <typename V> __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, V v)
+template <typename V, int AUX = 0> __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, V v)
 {
-    if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
-    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, AUX);
+    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, AUX);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
 template <int R0, int R1, int R2, int R3, bool SPLIT16 = (MFFT_TW16_SPLIT != 0)> struct Radices {
@@ -371,8 +375,14 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             // a slot beyond the batch re-reads the last signal and skips its stores: no branch here
             const int64_t bl = active ? b : a.batch - 1;
             const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
+            if constexpr (MFFT_FAST_BUF != 0 && TX >= 64) {
+                const auto rs = make_rsrc(src, (uint32_t)N * sizeof(C));
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
+                for (int e = 0; e < P; ++e) v[e] = buf_ld<C, MFFT_NT ? 2 : 0>(rs, (uint32_t)t * sizeof(C), TX * e * sizeof(C));
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
+            }
             if constexpr (VAR == V_HANN_POWER) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
@@ -507,6 +517,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     for (int e = 0; e < P; ++e) {
                         if (t + TX * e < a.n_out) dst[t + TX * e] = s[e];
                     }
+                } else if constexpr (MFFT_FAST_BUF != 0 && TX >= 64) {
+                    const auto ro = make_rsrc(dst, (uint32_t)N * sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < P; ++e) buf_st<T, MFFT_NT ? 2 : 0>(ro, (uint32_t)t * sizeof(T), TX * e * sizeof(T), s[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, s[e]);
