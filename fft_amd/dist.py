@@ -75,6 +75,61 @@ class Comm:
         return dst
 
 
+    def start_exchange(self, send_blocks, recv_blocks):
+        """Begin a personalised exchange of contiguous blocks: send_blocks[s] goes to rank s and
+        recv_blocks[r] receives what rank r sends here (the own block is copied locally).  Returns
+        a handle whose wait() completes it.  Point-to-point sends and receives in one group (what an
+        all-to-all is made of), so a caller can start the exchange of one chunk and keep
+        transforming the next while it is on the links."""
+        import torch
+        dist = self._dist
+        recv_blocks[self.rank].copy_(send_blocks[self.rank])
+        if self.world == 1:
+            return _Exchange([], [])
+        staged = self.backend == "gloo" and send_blocks[0].is_cuda       # rehearsal: through the host
+        ops, post = [], []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            dst_rank = peer if self.group is None else dist.get_global_rank(self.group, peer)
+            snd = torch.view_as_real(send_blocks[peer])
+            rcv = torch.view_as_real(recv_blocks[peer])
+            if staged:
+                snd = snd.cpu()
+                tmp = torch.empty(rcv.shape, dtype=rcv.dtype)
+                post.append((rcv, tmp))
+                rcv = tmp
+            ops.append(dist.P2POp(dist.isend, snd, dst_rank, self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, dst_rank, self.group))
+        return _Exchange(dist.batch_isend_irecv(ops), post)
+
+
+class _Exchange:
+    def __init__(self, works, post):
+        self._works, self._post = works, post
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        for dst, src in self._post:
+            dst.copy_(src)
+        self._works, self._post = [], []
+
+
+def _chunk_count(requested, rows, world):
+    """How many row chunks the first exchange is cut into: the largest divisor of `rows` not
+    above the request (default 4 with several ranks, MFFT_DIST_CHUNKS overrides), 1 for one rank."""
+    import os
+    if world == 1:
+        return 1
+    if requested is None:
+        requested = int(os.environ.get("MFFT_DIST_CHUNKS", "4"))
+    c = max(1, min(int(requested), rows))
+    while rows % c:
+        c -= 1
+    return c
+
+
 # --------------------------------------------------------------------------- local operations
 
 class HipOps:
@@ -170,7 +225,7 @@ class _Buffers:
 
 # --------------------------------------------------------------------------- 2-D slab / pencil
 
-def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
+def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=None):
     """2-D forward DFT of an n0 x n1 array distributed by row slabs.
 
     ``a_local``: this rank's n0/P consecutive rows, flat complex tensor of (n0/P)*n1
@@ -184,6 +239,10 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
     Local passes over the slab: row FFTs (stored already packed per destination), then the
     column FFTs on the strided columns where the exchange left them (no transpose), then --
     only with P > 1 and restore_layout -- one block copy that unpacks the way back.
+
+    With several ranks the first exchange is pipelined: the rows are transformed in `chunks`
+    groups, and a group's blocks travel (grouped point-to-point sends, each landing as a
+    contiguous row range of the column matrix) while the next group is transformed.
     """
     P = comm.world
     if n0 % P or n1 % P:
@@ -195,8 +254,22 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
 
     # row FFTs; bin k of local row i is stored at [k // W][i][k % W]: already packed per destination
     x = bufs.free(a_local)
-    ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
-    cur = comm.all_to_all(bufs.free(x), x)         # cur[r][i][c]: (n0 x W), row r*R + i, local column c
+    C = _chunk_count(chunks, R, P)
+    if C == 1:
+        ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
+        cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c]: (n0 x W), row r*R + i, local column c
+    else:
+        Rc = R // C
+        cur = bufs.free(x)
+        pending = []
+        for c in range(C):
+            sb = x[c * Rc * n1:(c + 1) * Rc * n1]  # this group's send buffer: [s][i][col], P x Rc x W
+            ops.fft(a_local[c * Rc * n1:(c + 1) * Rc * n1], sb, n=n1, batch=Rc, out_layout=(W, W, Rc * W))
+            sends = [sb[s * Rc * W:(s + 1) * Rc * W] for s in range(P)]
+            recvs = [cur[(r * R + c * Rc) * W:(r * R + (c + 1) * Rc) * W] for r in range(P)]
+            pending.append(comm.start_exchange(sends, recvs))
+        for h in pending:
+            h.wait()
     nxt = bufs.free(cur)
     if ops.columns_ok(n0, W, cur):
         ops.fft_columns(cur, nxt, n=n0, inner=W)
@@ -220,7 +293,7 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False):
 
 # --------------------------------------------------------------------------- large 1-D four-step
 
-def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
+def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=None):
     """Forward DFT of ONE signal of n = n1*n2 points distributed in contiguous chunks.
 
     ``x_local``: this rank's n/P consecutive samples (flat complex tensor).  With
@@ -236,7 +309,8 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
     Local passes: one block copy that packs the first exchange, the n1-point FFTs on the
     strided columns with the inter-step twiddle folded into their last store, the n2-point
     FFTs reading the second exchange's blocks in place (segmented load), and for natural
-    order one transpose after the third exchange.
+    order one transpose after the third exchange.  With several ranks the first exchange is
+    pipelined in `chunks` row groups like fft2_slab's.
     """
     P = comm.world
     if n1 % P or n2 % P:
@@ -252,8 +326,22 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True):
         cur = x_local
     else:
         x = bufs.free(x_local)
-        ops.swap_axes(x_local, x, a=R1, b=P, w=W2)
-        cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
+        C = _chunk_count(chunks, R1, P)
+        if C == 1:
+            ops.swap_axes(x_local, x, a=R1, b=P, w=W2)
+            cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
+        else:
+            Rc = R1 // C
+            cur = bufs.free(x)
+            pending = []
+            for c in range(C):
+                sb = x[c * Rc * n2:(c + 1) * Rc * n2]      # [s][i][col], P x Rc x W2
+                ops.swap_axes(x_local[c * Rc * n2:(c + 1) * Rc * n2], sb, a=Rc, b=P, w=W2)
+                sends = [sb[s * Rc * W2:(s + 1) * Rc * W2] for s in range(P)]
+                recvs = [cur[(r * R1 + c * Rc) * W2:(r * R1 + (c + 1) * Rc) * W2] for r in range(P)]
+                pending.append(comm.start_exchange(sends, recvs))
+            for h in pending:
+                h.wait()
     nxt = bufs.free(cur)
     if ops.columns_ok(n1, W2, cur):
         # A[k1][c] = W_n^(k1 * (rank*W2 + c)) * sum_j1 W_n1^(j1 k1) cur[j1][c]

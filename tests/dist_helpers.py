@@ -107,8 +107,10 @@ def worker(rank, world, port, use_gpu, results_dir):
                 F = np.fft.fft2(A)
                 R, W = n0 // world, n1 // world
                 mine = torch.from_numpy(A[rank * R:(rank + 1) * R].reshape(-1).copy()).to(dev)
-                out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False).cpu().numpy().reshape(n0, W)
-                errs[f"fft2_cols_{tag}_{n0}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
+                for chunks in (1, 2, 4, None):
+                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False, chunks=chunks)
+                    out = out.cpu().numpy().reshape(n0, W)
+                    errs[f"fft2_cols_{tag}_{n0}_{chunks}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
                 out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True).cpu().numpy().reshape(R, n1)
                 errs[f"fft2_rows_{tag}_{n0}"] = rel_l2(out, F[rank * R:(rank + 1) * R])
                 assert np.array_equal(mine.cpu().numpy(), A[rank * R:(rank + 1) * R].reshape(-1)), "input clobbered"
@@ -122,10 +124,11 @@ def worker(rank, world, port, use_gpu, results_dir):
                 mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
                 out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True).cpu().numpy()
                 errs[f"fft1d_N_{tag}_{n1f}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
-                out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=False).cpu().numpy()
                 R1 = n1f // world
                 want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
-                errs[f"fft1d_T_{tag}_{n1f}"] = rel_l2(out.reshape(R1, n2f), want)
+                for chunks in (1, 2, 3, None):
+                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=False, chunks=chunks).cpu().numpy()
+                    errs[f"fft1d_T_{tag}_{n1f}_{chunks}"] = rel_l2(out.reshape(R1, n2f), want)
                 assert np.array_equal(mine.cpu().numpy(), x[rank * chunk:(rank + 1) * chunk]), "input clobbered"
 
         # ---- batch sharding: no collective ------------------------------------------

@@ -48,6 +48,10 @@ def test_two_ranks_gloo_cpu():
     _spawn(2, use_gpu=False)
 
 
+def test_four_ranks_gloo_cpu():
+    _spawn(4, use_gpu=False)
+
+
 def test_single_rank_cpu_standin():
     """world_size 1 degenerates to local copies: same code path, no process group."""
     import torch

@@ -27,10 +27,20 @@ class FakeComm:
     def __init__(self, world, rank=0):
         self.world, self.rank, self.backend = world, rank, "none"
         self.exchanges = 0
+        self.chunks_seen = 4          # the decompositions' default chunk count with several ranks
 
     def all_to_all(self, dst, src):
         self.exchanges += 1
         return src
+
+    def start_exchange(self, send_blocks, recv_blocks):
+        """One chunk of the pipelined first exchange: counted as a fraction of an all-to-all."""
+        self.exchanges += 1.0 / self.chunks_seen if self.chunks_seen else 0
+
+        class _Done:
+            def wait(self):
+                pass
+        return _Done()
 
 
 def timed(fn, reps=5):
@@ -77,7 +87,7 @@ def main():
                 t = timed(fn)
                 comm.exchanges = 0
                 fn()
-                ex = comm.exchanges if P > 1 else 0
+                ex = int(round(comm.exchanges)) if P > 1 else 0
                 per_link = local.numel() * esz / P
                 t_x = ex * per_link / (LINK_GBS * 1e9)
                 key = (name, restore)
