@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--n", type=int, default=N_POINTS, help="transform length (default: the headline 1024)")
     ap.add_argument("--batch", type=int, default=BATCH, help="signals per GPU (default: the headline 65536)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short timings of BASELINE configs 3-5 (one GPU) appended as `other_configs`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="all ranks share cuda:0 (use with --backend gloo on a one-GPU box; not a measurement)")
@@ -114,6 +116,85 @@ def cpu_multicore(x_host, n, budget_s=5.0):
     return {"value": flops / elapsed / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes over all {rows} signals = {elapsed:.1f} s; window * x -> "
                       f"scipy.fft.fft(workers={cores}) -> re^2+im^2, scipy {scipy.__version__}"}
+
+
+def secondary_configs(with_cpu):
+    """Short single-GPU timings of the other BASELINE configurations (parity-test cases, not the
+    headline): config 3 (2^24 complex64), config 4 (16384^2 complex64 through the slab
+    decomposition, one rank) and config 5 (2^31 complex128 through the four-step decomposition,
+    one rank).  Each entry: ms per transform, GFLOP/s (5 N log2 N) and algorithmic GB/s (one read +
+    one write of the data); failures are recorded, never raised."""
+    import numpy as np
+    import torch
+    import fft_amd
+    from fft_amd import dist as fd
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3 / reps)
+        return best
+
+    def entry(t, points, log2n, esz, **extra):
+        d = {"ms": t * 1e3, "gflops": 5.0 * points * log2n / t / 1e9, "gbs_algorithmic": 2.0 * esz * points / t / 1e9,
+             "roofline_frac": 2.0 * esz * points / t / 1e9 / HBM_PEAK_GBS}
+        d.update(extra)
+        return d
+
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        n = 1 << 24
+        x = torch.view_as_complex(torch.randn((n, 2), dtype=torch.float32, device="cuda"))
+        y = torch.empty_like(x)
+        plan = fft_amd.Plan(n, dtype=fft_amd.C64)
+        t = timed(lambda: plan.exec(x, y, stream=stream), 30)
+        extra = {"launches": plan.launches}
+        if with_cpu:
+            xh = x.cpu().numpy()
+            t0 = time.perf_counter()
+            np.fft.fft(xh)
+            extra["cpu_numpy_ms_1core"] = (time.perf_counter() - t0) * 1e3
+        out["config3_1d_2pow24_c64"] = entry(t, n, 24, 8, **extra)
+        plan.destroy()
+        del x, y
+    except Exception as exc:                                  # noqa: BLE001 - a side measurement must not sink the headline
+        out["config3_1d_2pow24_c64"] = {"error": repr(exc)[:200]}
+    comm, ops = fd.Comm(), fd.HipOps()
+    try:
+        n = 16384
+        a = torch.view_as_complex(torch.randn((n * n, 2), dtype=torch.float32, device="cuda"))
+        t = timed(lambda: fd.fft2_slab(a, n, n, comm, ops, restore_layout=True), 3)
+        out["config4_2d_16384x16384_c64_one_gpu"] = entry(t, n * n, 28, 8, local_passes=3)
+        del a
+    except Exception as exc:                                  # noqa: BLE001
+        out["config4_2d_16384x16384_c64_one_gpu"] = {"error": repr(exc)[:200]}
+    ops.close()
+    torch.cuda.empty_cache()
+    try:
+        free, _ = torch.cuda.mem_get_info()
+        lg = 31 if free >= 180 * (1 << 30) else 28
+        n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+        x = torch.empty(n1 * n2, dtype=torch.complex128, device="cuda")
+        xr = torch.view_as_real(x)
+        for lo in range(0, n1 * n2, 1 << 27):
+            xr[lo:lo + (1 << 27)].normal_()
+        t = timed(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True), 1)
+        out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5)
+        del x, xr
+    except Exception as exc:                                  # noqa: BLE001
+        out["config5_1d_c128_one_gpu"] = {"error": repr(exc)[:200]}
+    ops.close()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -209,9 +290,13 @@ def main():
         line["cpu_baseline_multicore"] = cpu_multicore(x_host, n)
     else:
         line["cpu_baseline"] = None
+    plan.destroy()
+    del d_x, d_s
+    if rank == 0 and world == 1 and not args.no_secondary and n == N_POINTS and batch == BATCH:
+        torch.cuda.empty_cache()
+        line["other_configs"] = secondary_configs(with_cpu=not args.no_cpu)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    plan.destroy()
     if distributed:
         dist.destroy_process_group()
 
