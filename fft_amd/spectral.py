@@ -108,8 +108,44 @@ def _refine_log_parabola(x, y, i):
     return x[i] + ((l0 - l2) / curv) * (0.5 * (x[i + 1] - x[i - 1]))
 
 
+_hann_cache: "OrderedDict[int, np.ndarray]" = OrderedDict()
+
+
+def _hanning(m: int) -> np.ndarray:
+    """np.hanning(m) (final2.py:139), kept read-only for the few lengths a session uses."""
+    with _axis_lock:
+        w = _hann_cache.get(m)
+        if w is not None:
+            _hann_cache.move_to_end(m)
+            return w
+    w = np.hanning(m)
+    w.setflags(write=False)
+    with _axis_lock:
+        _hann_cache[m] = w
+        while len(_hann_cache) > 8:
+            _hann_cache.popitem(last=False)
+    return w
+
+
 def _window_of(f_t, use_hann):
-    return np.hanning(len(f_t)) if use_hann else np.ones_like(f_t)
+    return _hanning(len(f_t)) if use_hann else np.ones_like(f_t)
+
+
+def _by_height(cand, heights, first=64):
+    """Candidates in order of decreasing height (np.argsort(...)[::-1], final2.py:161,
+    streamlit_app_combined.py:222), sorting only the tallest `first` unless the caller walks past
+    them: the guard-spaced pick usually stops within the first few."""
+    if cand.size <= 4 * first:
+        yield from cand[np.argsort(heights)[::-1]]
+        return
+    top = np.argpartition(heights, -first)[-first:]
+    top = top[np.argsort(heights[top])[::-1]]
+    yield from cand[top]
+    seen = np.zeros(cand.size, bool)
+    seen[top] = True
+    for i in np.argsort(heights)[::-1]:
+        if not seen[i]:
+            yield cand[i]
 
 
 def _normal_equations(x, win, times, E_cols, mu=0.0):
@@ -185,17 +221,16 @@ def fft_from_timeseries(
     domega = TWO_PI / (span + 1e-12)
     if include_dc:
         if S[0] > 0:
-            cand = np.unique(np.concatenate(([0], cand)))
+            cand = np.concatenate(([0], cand))          # interior maxima start at 1: still ascending and unique
     else:
         cand = cand[np.abs(omega[cand]) > dc_guard * domega]
     if cand.size == 0:
         return np.array([]), np.array([]), -omega, S_norm
 
-    by_height = cand[np.argsort(S[cand])[::-1]]
     guard = guard_mult * domega
     want = max(n_levels, 1)
     chosen = []
-    for k in by_height:
+    for k in _by_height(cand, S[cand]):
         if all(abs(omega[k] - omega[j]) > guard for j in chosen):
             chosen.append(int(k))
         if len(chosen) >= want:
@@ -204,7 +239,7 @@ def fft_from_timeseries(
 
     if E_hat.size > 64:
         raise ValueError("at most 64 spectral lines can be fitted at once")
-    G, r, yy = _normal_equations(f_t, np.hanning(n0) if use_hann else None, times, E_hat)
+    G, r, yy = _normal_equations(f_t, _hanning(n0) if use_hann else None, times, E_hat)
     _, p, _ = _solve_normal(G, r, yy, np.arange(E_hat.size))
     if post_prune:
         keep = p > min_weight
@@ -298,11 +333,10 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
     omega = _omega_axis(nfft, dt).copy()
     if cand.size == 0:
         return np.array([]), np.array([]), omega, S, mu
-    by_height = cand[np.argsort(S[cand])][::-1]
     tol = TWO_PI / (times[-1] - times[0] + 1e-12)
     limit = max(n_peaks * 3, n_peaks)
     chosen = []
-    for k in by_height:
+    for k in _by_height(cand, S[cand]):
         if len(chosen) >= limit:
             break
         if all(abs(abs(omega[k]) - abs(omega[j])) > 0.6 * tol for j in chosen):

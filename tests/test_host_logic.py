@@ -127,3 +127,16 @@ def test_engine_dtype_promotion():
     assert engine_dtype(np.zeros(2, np.complex128)) == (_lib.C128, False)
     assert engine_dtype(np.zeros(2, np.float64)) == (_lib.C128, True)
     assert engine_dtype(np.zeros(2, np.int32)) == (_lib.C128, True)
+
+
+def test_by_height_matches_full_sort():
+    from fft_amd.spectral import _by_height
+    rng = np.random.default_rng(8)
+    for size in (0, 1, 10, 256, 257, 5000):
+        cand = np.sort(rng.choice(100000, size=size, replace=False))
+        h = rng.random(size)
+        assert list(_by_height(cand, h)) == list(cand[np.argsort(h)[::-1]])
+    h = np.repeat(rng.random(50), 20)                    # ties across the partition boundary
+    cand = np.arange(1000)
+    got = list(_by_height(cand, h))
+    assert sorted(got) == list(range(1000)) and np.all(np.diff(h[got]) <= 0)
