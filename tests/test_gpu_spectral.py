@@ -293,3 +293,25 @@ def test_peak_buffer_overflow_reruns_on_device(fa):
     plan_S, stats, few = fa.npfft.cached_plan(n0 * pad, n0, 1, fa.C128, fa.POWER | fa.STATS).exec_host_peaks(
         x, scale=0.01, capacity=8)
     assert isinstance(few, int) and few == want.size
+
+
+def test_non_finite_samples_behave_like_the_reference(fa):
+    """A NaN (or Inf) sample poisons the whole spectrum in numpy's transform; the estimator then
+    finds no peak and returns the NaN spectrum unnormalised (S.max() > 0 is False): same here."""
+    t = np.arange(300) * 0.05
+    f = np.exp(-1j * 1.3 * t)
+    for bad in (np.nan, np.inf):
+        g = f.copy()
+        g[17] = bad
+        y = fa.fft(g)
+        assert np.all(np.isnan(y.real) | np.isnan(y.imag))
+        with np.errstate(all="ignore"):
+            Eo, po, axo, So = so.fft_from_timeseries(g, t, n_levels=3, pad_factor=4)
+        E, p, ax, S = fa.fft_from_timeseries(g, t, n_levels=3, pad_factor=4)
+        assert E.size == Eo.size == 0 and p.size == po.size == 0
+        assert np.array_equal(ax, axo) and np.all(np.isnan(S)) and np.all(np.isnan(So))
+    # a batch: only the poisoned signal is affected
+    x = _rand((4, 1024), 3, np.complex64)
+    x[2, 100] = np.nan
+    y = fa.fft(x)
+    assert np.all(np.isnan(y[2])) and rel_l2(y[[0, 1, 3]], np.fft.fft(x[[0, 1, 3]].astype(np.complex128))) < 1e-5
