@@ -795,7 +795,8 @@ struct Plan {
     hipStream_t s_run = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int64_t pipe_slab = 0;        // signals per slab
-    int64_t* d_peaks = nullptr;   // [0] = count, [1..] = candidate indices (mfft_exec_host_peaks)
+    int64_t* d_peaks = nullptr;   // {max, sum, centroid} | count | candidate indices (mfft_exec_host_peaks)
+    int64_t* h_peaks = nullptr;   // pinned mirror of d_peaks
     int64_t peak_cap = 0;
     int64_t workspace = 0;
     int launches = 1;
@@ -824,7 +825,7 @@ static void plan_free(Plan* p)
     for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
                     (void*)p->d_peaks})
         if (q) (void)hipFree(q);
-    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1]})
+    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks})
         if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1]})
         if (e) (void)hipEventDestroy(e);
@@ -1419,18 +1420,35 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
     a.m = m;
     a.mu = mu;
     for (int i = 0; i < 64; ++i) a.E[i] = i < m ? h_E[i] : 0.0;
-    // one device block: x (2n) | times (n) | win (n) | results (2mm + 2m + 1)
+    // One device block and one pinned host block per device, kept and grown as needed (a call takes
+    // ~50 us; concurrent callers queue on the lock):  x (2n) | times (n) | win (n) | results (2mm + 2m + 1)
+    struct Scratch { double* dev = nullptr; double* pin = nullptr; size_t cap = 0; };
+    static std::mutex pool_mu;
+    static Scratch pool[64];
+    int device = 0;
+    MFFT_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64) { set_error("device index out of range"); return MFFT_E_UNSUPPORTED; }
     const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
     const size_t doubles = 4 * (size_t)n + nres;
-    double* d = nullptr;
-    MFFT_HIP(hipMalloc((void**)&d, doubles * sizeof(double)));
-    double* d_x = d;
-    double* d_t = d + 2 * n;
-    double* d_w = d + 3 * n;
-    double* d_res = d + 4 * n;
-    hipError_t e = hipMemcpy(d_x, h_x, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_t, h_times, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && h_win) e = hipMemcpy(d_w, h_win, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    std::lock_guard<std::mutex> lock(pool_mu);
+    Scratch& sc = pool[device];
+    if (sc.cap < doubles) {
+        if (sc.dev) (void)hipFree(sc.dev);
+        if (sc.pin) (void)hipHostFree(sc.pin);
+        sc = Scratch{};
+        const size_t want = doubles + doubles / 2;
+        MFFT_HIP(hipMalloc((void**)&sc.dev, want * sizeof(double)));
+        MFFT_HIP(hipHostMalloc((void**)&sc.pin, want * sizeof(double), hipHostMallocDefault));
+        sc.cap = want;
+    }
+    double* d_x = sc.dev;
+    double* d_t = sc.dev + 2 * n;
+    double* d_w = sc.dev + 3 * n;
+    double* d_res = sc.dev + 4 * n;
+    memcpy(sc.pin, h_x, 2 * (size_t)n * sizeof(double));
+    memcpy(sc.pin + 2 * n, h_times, (size_t)n * sizeof(double));
+    if (h_win) memcpy(sc.pin + 3 * n, h_win, (size_t)n * sizeof(double));
+    hipError_t e = hipMemcpyAsync(sc.dev, sc.pin, (h_win ? 4 : 3) * (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr);
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, nres * sizeof(double), nullptr);
     if (e == hipSuccess) {
         int64_t blocks = (n + 255) / 256;
@@ -1444,12 +1462,12 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
             e = hipGetLastError();
         }
     }
-    std::vector<double> res(nres);
-    if (e == hipSuccess) e = hipMemcpy(res.data(), d_res, nres * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    double* res = sc.pin + 4 * n;
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d_res, nres * sizeof(double), hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return hip_fail(e, "lsq_normal", __FILE__, __LINE__);
-    memcpy(h_G, res.data(), 2 * (size_t)m * m * sizeof(double));
-    memcpy(h_r, res.data() + 2 * (size_t)m * m, 2 * (size_t)m * sizeof(double));
+    memcpy(h_G, res, 2 * (size_t)m * m * sizeof(double));
+    memcpy(h_r, res + 2 * (size_t)m * m, 2 * (size_t)m * sizeof(double));
     *h_yy = res[nres - 1];
     return MFFT_OK;
 }
@@ -1483,23 +1501,49 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
 {
     if (!plan || !h_in || !h_out || !h_idx || !h_count || capacity < 1) { set_error("null argument"); return MFFT_E_INVALID; }
     Plan* p = reinterpret_cast<Plan*>(plan);
-    if (!(p->flags & MFFT_POWER) || p->batch != 1) { set_error("peak scan needs a one-signal MFFT_POWER plan"); return MFFT_E_INVALID; }
-    int rc = mfft_exec_host(plan, h_in, h_out, scale, mu, t0, dt, h_stats);
-    if (rc) return rc;
+    if (!(p->flags & MFFT_POWER) || p->batch != 1 || p->kind == Plan::COLUMNS) { set_error("peak scan needs a one-signal MFFT_POWER plan"); return MFFT_E_INVALID; }
+    if ((p->flags & MFFT_STATS) && !h_stats) { set_error("plan has MFFT_STATS but h_stats is null"); return MFFT_E_INVALID; }
+    if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg) {
+        set_error("host entry points serve dense layouts only");
+        return MFFT_E_UNSUPPORTED;
+    }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
     std::lock_guard<std::mutex> lock(p->mu);
+    const size_t rs = real_size(p->dtype);
+    const size_t in_bytes = (size_t)p->n_in * rs * ((p->flags & MFFT_REAL_IN) ? 1 : 2);
+    const size_t out_bytes = (size_t)p->n * rs;
+    if (!p->d_in) MFFT_HIP(hipMalloc(&p->d_in, in_bytes));
+    if (!p->d_out) MFFT_HIP(hipMalloc(&p->d_out, out_bytes));
+    // one result block: {max, sum, centroid} | count | indices, mirrored in pinned host memory so
+    // that the statistics, the count and the first indices come back in a single copy
+    constexpr int64_t kHead = 4, kFirst = 8192;
     if (p->peak_cap < capacity) {
         if (p->d_peaks) (void)hipFree(p->d_peaks);
-        p->d_peaks = nullptr;
-        MFFT_HIP(hipMalloc((void**)&p->d_peaks, sizeof(int64_t) * (size_t)(capacity + 1)));
+        if (p->h_peaks) (void)hipHostFree(p->h_peaks);
+        p->d_peaks = nullptr; p->h_peaks = nullptr; p->peak_cap = 0;
+        MFFT_HIP(hipMalloc((void**)&p->d_peaks, sizeof(int64_t) * (size_t)(capacity + kHead)));
+        MFFT_HIP(hipHostMalloc((void**)&p->h_peaks, sizeof(int64_t) * (size_t)(capacity + kHead), hipHostMallocDefault));
         p->peak_cap = capacity;
     }
-    rc = mfft_local_maxima(p->d_out, p->n, p->dtype, p->d_peaks + 1, capacity, p->d_peaks, nullptr);
+    double* d_stats = reinterpret_cast<double*>(p->d_peaks);
+    MFFT_HIP(hipMemcpyAsync(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice, nullptr));
+    MFFT_HIP(hipMemsetAsync(p->d_peaks, 0, sizeof(int64_t) * kHead, nullptr));
+    int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, d_stats, nullptr);
     if (rc) return rc;
-    MFFT_HIP(hipMemcpy(h_count, p->d_peaks, sizeof(int64_t), hipMemcpyDeviceToHost));
+    rc = mfft_local_maxima(p->d_out, p->n, p->dtype, p->d_peaks + kHead, capacity, p->d_peaks + 3, nullptr);
+    if (rc) return rc;
+    const int64_t first = capacity < kFirst ? capacity : kFirst;
+    MFFT_HIP(hipMemcpyAsync(p->h_peaks, p->d_peaks, sizeof(int64_t) * (size_t)(kHead + first), hipMemcpyDeviceToHost, nullptr));
+    MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));      // synchronises the stream
+    MFFT_HIP(hipStreamSynchronize(nullptr));
+    if (h_stats) memcpy(h_stats, p->h_peaks, 3 * sizeof(double));
+    *h_count = p->h_peaks[3];
     const int64_t take = *h_count < capacity ? *h_count : capacity;
-    if (take > 0) MFFT_HIP(hipMemcpy(h_idx, p->d_peaks + 1, sizeof(int64_t) * (size_t)take, hipMemcpyDeviceToHost));
+    if (take > first)
+        MFFT_HIP(hipMemcpy(p->h_peaks + kHead + first, p->d_peaks + kHead + first, sizeof(int64_t) * (size_t)(take - first),
+                           hipMemcpyDeviceToHost));
+    if (take > 0) memcpy(h_idx, p->h_peaks + kHead, sizeof(int64_t) * (size_t)take);
     return MFFT_OK;
 }
 
