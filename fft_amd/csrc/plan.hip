@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "tile_kernel.h"
+#include "wave_kernel.h"
 
 namespace mfft {
 
@@ -477,6 +478,7 @@ struct Pow2Engine {
     bool single = true;
     LdsGeometry geo{};
     void* d_tw = nullptr;               // single-kernel twiddles
+    void* d_wave_tw = nullptr;          // W_N^j, j < N/2, for the lane-distributed kernel (shortest lengths)
     std::vector<GlobalPass> passes;     // tiled decomposition
     void* work[2] = {nullptr, nullptr};
     void* stage_in = nullptr;           // dense copies around a general single-kernel transform whose
@@ -549,7 +551,16 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         if (!lds_geometry(dtype, log2n, &geo)) { set_error("no single-kernel geometry"); return MFFT_E_UNSUPPORTED; }
         build_lds_twiddles(geo, &re, &im);
         bytes += (int64_t)re.size() * 2 * (int64_t)real_size(dtype);
-        return upload_complex_dt(dtype, re, im, &d_tw);
+        int rc = upload_complex_dt(dtype, re, im, &d_tw);
+        if (rc) return rc;
+        const bool wave_ok = dtype == MFFT_C64 ? (log2n >= kWaveMinLog2C64 && log2n <= kWaveMaxLog2C64)
+                                               : (log2n >= kWaveMinLog2C128 && log2n <= kWaveMaxLog2C128);
+        if (wave_ok && !getenv("MFFT_NO_WAVE")) {
+            re.resize((size_t)(n / 2)); im.resize((size_t)(n / 2));
+            for (int64_t j = 0; j < n / 2; ++j) unit_root(j, n, &re[(size_t)j], &im[(size_t)j]);
+            rc = upload_complex_dt(dtype, re, im, &d_wave_tw);
+        }
+        return rc;
     }
     single = false;
     std::vector<int> split;
@@ -624,6 +635,8 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
 void Pow2Engine::release()
 {
     if (d_tw) (void)hipFree(d_tw);
+    if (d_wave_tw) (void)hipFree(d_wave_tw);
+    d_wave_tw = nullptr;
     for (auto& gp : passes)
         for (void* q : {gp.d_tw, gp.d_lo, gp.d_hi})
             if (q) (void)hipFree(q);
@@ -670,6 +683,17 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.out_lseg = io.out_seg ? ilog2(io.out_seg) : 30;
         }
         else variant = io.power ? V_GEN_POWER : V_GEN_CPLX;
+        if (variant == V_PLAIN && d_wave_tw) {
+            // shortest lengths: the signal lives across lanes (DPP / swizzle exchanges, 16 B per lane)
+            WaveArgs<T> w{};
+            w.in = static_cast<const cx<T>*>(io.in);
+            w.out = static_cast<cx<T>*>(io.out);
+            w.tw = static_cast<const cx<T>*>(d_wave_tw);
+            w.units = nb * n * (int64_t)sizeof(cx<T>) / 16;
+            w.scale = io.scale;
+            if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, w, s);
+            else return launch_wave_c128(log2n, w, s);
+        }
         const bool general = variant == V_GEN_POWER || variant == V_GEN_CPLX;
         const bool stage_i = general && io.in_seg > 0, stage_o = general && io.out_seg > 0;
         const size_t in_esz = io.real_in ? sizeof(T) : sizeof(cx<T>), out_esz = io.power ? sizeof(T) : sizeof(cx<T>);
