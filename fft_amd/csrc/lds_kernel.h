@@ -41,6 +41,9 @@
 #ifndef MFFT_FAST_BUF
 #define MFFT_FAST_BUF 0      // tuning aid: 1 = buffer-resource accesses (scalar offsets) in the plain / hann+power variants
 #endif
+#ifndef MFFT_PREFETCH
+#define MFFT_PREFETCH 0      // 1 = wave-private fast variants load the next signal before transforming the current one
+#endif
 #ifndef MFFT_TW16_SPLIT
 #define MFFT_TW16_SPLIT 1    // radix-16 passes keep w^1,w^2,w^3,w^4,w^8,w^12 and form the other nine by one multiply
 #endif
@@ -353,6 +356,18 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     }
 
     const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
+    // Software pipeline (wave-private signals, fast variants): the next signal's loads are issued
+    // before the current one is transformed, so the bus never waits for the butterflies.
+    constexpr bool PREFETCH = MFFT_PREFETCH != 0 && !GENERAL && VAR != V_SEG && TX <= 64;
+    C vn[PREFETCH ? P : 1];
+    if constexpr (PREFETCH) {
+        if ((int64_t)blockIdx.x < groups) {
+            const int64_t b1 = (int64_t)blockIdx.x * SLOTS + slot;
+            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + (b1 < a.batch ? b1 : a.batch - 1) * a.in_stride;
+#pragma unroll
+            for (int e = 0; e < P; ++e) vn[e] = ld_stream(src + t + TX * e);
+        }
+    }
     for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
         const int64_t b = g * SLOTS + slot;
         const bool active = b < a.batch;
@@ -379,6 +394,15 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 const auto rs = make_rsrc(src, (uint32_t)N * sizeof(C));
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = buf_ld<C, MFFT_NT ? 2 : 0>(rs, (uint32_t)t * sizeof(C), TX * e * sizeof(C));
+            } else if constexpr (PREFETCH) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = vn[e];
+                // the group after this one (re-reads this one at the end of the batch: no branch)
+                const int64_t gn = g + gridDim.x < groups ? g + gridDim.x : g;
+                const int64_t bn = gn * SLOTS + slot;
+                const C* __restrict__ nsrc = reinterpret_cast<const C*>(a.in) + (bn < a.batch ? bn : a.batch - 1) * a.in_stride;
+#pragma unroll
+                for (int e = 0; e < P; ++e) vn[e] = ld_stream(nsrc + t + TX * e);
             } else {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
