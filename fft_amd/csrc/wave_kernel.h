@@ -1,4 +1,4 @@
-// Lane-distributed FFT for the shortest transforms: a signal of N <= 64 (complex64) or N <= 32
+// Lane-distributed FFT for the shortest transforms: a signal of N <= 128 (complex64) or N <= 64
 // (complex128) points lives across the lanes of one wavefront, 16 bytes per lane, and never
 // touches LDS memory.
 //
@@ -13,8 +13,9 @@
 //     lane with bit m set:    x <- (x_partner - x) * W_{2h}^(i mod h)
 //
 // The partner exchange is a DPP quad permutation (m = 1, 2) or a ds_swizzle bit-mask pattern
-// (m = 4, 8, 16): register-to-register through the cross-lane network, no LDS allocation, no
-// barrier.  The last stage of a complex64 signal (h = 1) pairs the two elements a lane holds.
+// (m = 4, 8, 16), a ds_bpermute for m = 32: register-to-register through the cross-lane network,
+// no LDS allocation, no barrier.  The last stage of a complex64 signal (h = 1) pairs the two
+// elements a lane holds.
 // Decimation in frequency leaves bin bitrev(i) at element i; the store scatters within the
 // wave's own contiguous KiB, so every cache line it touches is written completely.
 #pragma once
@@ -30,11 +31,13 @@ template <typename T> struct WaveArgs {
     T scale;
 };
 
-// value of lane (lane ^ MASK), MASK in {1, 2, 4, 8, 16}
+// value of lane (lane ^ MASK), MASK in {1, 2, 4, 8, 16, 32}
 template <int MASK> __device__ __forceinline__ int xor_lane_i32(int v)
 {
     if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
     else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 32)                                                            // across the two halves
+        return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ 32) << 2), v);
     else return __builtin_amdgcn_ds_swizzle(v, (MASK << 10) | 0x1F);                          // bit-mask mode: xor MASK
 }
 template <int MASK> __device__ __forceinline__ float xor_lane(float v)
@@ -67,9 +70,9 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
     constexpr int N = 1 << LOG2N;
     constexpr int K = 16 / (int)sizeof(cx<T>);       // elements per lane: 2 (complex64), 1 (complex128)
     constexpr int LOG2K = K == 2 ? 1 : 0;
-    constexpr int LANES = N / K;                     // lanes per signal (1..32)
+    constexpr int LANES = N / K;                     // lanes per signal (2..64)
     constexpr int XS = LOG2N - LOG2K;                // cross-lane stages
-    static_assert(LANES >= 1 && LANES <= 32, "signal must fit 32 lanes");
+    static_assert(LANES >= 1 && LANES <= 64, "signal must fit one wavefront");
     using C = cx<T>;
     using V4 = unsigned int __attribute__((ext_vector_type(4)));
 
@@ -115,6 +118,7 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             // ---- radix-2 DIF across lanes ---------------------------------------------------------
+            if constexpr (XS >= 1 && LANES >= 64) wave_stage<T, K, 32>(x[u], w[XS - 6], !(li & 32));
             if constexpr (XS >= 1 && LANES >= 32) wave_stage<T, K, 16>(x[u], w[XS - 5], !(li & 16));
             if constexpr (XS >= 1 && LANES >= 16) wave_stage<T, K, 8>(x[u], w[XS - 4], !(li & 8));
             if constexpr (XS >= 1 && LANES >= 8) wave_stage<T, K, 4>(x[u], w[XS - 3], !(li & 4));
@@ -156,15 +160,15 @@ int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
     return MFFT_OK;
 }
 
-// complex64: 4..64 points, complex128: 2..32 points
+// complex64: 4..128 points, complex128: 2..64 points
 template <typename T>
 int launch_wave_any(int log2n, const WaveArgs<T>& a, hipStream_t s)
 {
-    constexpr int MAXLOG = sizeof(T) == 4 ? 6 : 5;
+    constexpr int MAXLOG = sizeof(T) == 4 ? 7 : 6;
     constexpr int MINLOG = sizeof(T) == 4 ? 2 : 1;
     switch (log2n) {
 #define MFFT_W(L) case L: if constexpr (L >= MINLOG && L <= MAXLOG) return launch_wave_one<T, L>(a, s); else break;
-        MFFT_W(1) MFFT_W(2) MFFT_W(3) MFFT_W(4) MFFT_W(5) MFFT_W(6)
+        MFFT_W(1) MFFT_W(2) MFFT_W(3) MFFT_W(4) MFFT_W(5) MFFT_W(6) MFFT_W(7)
 #undef MFFT_W
     }
     set_error("length not served by the lane-distributed kernel");
