@@ -25,8 +25,9 @@ namespace mfft {
 
 template <typename T> struct WaveArgs {
     const cx<T>* in;
-    cx<T>* out;
+    void* out;             // complex bins, or (HANNPOWER) the real power spectrum
     const cx<T>* tw;       // W_N^j = exp(-2*pi*i*j/N), j < N/2
+    const T* win;          // HANNPOWER: window of N samples
     int64_t units;         // 16-byte units in the whole batch = batch * N / K
     T scale;
 };
@@ -64,7 +65,8 @@ __device__ __forceinline__ void wave_stage(cx<T> (&x)[K], const cx<T> (&w)[K], b
     }
 }
 
-template <typename T, int LOG2N, int UNROLL>
+// HANNPOWER: x[j] *= win[j] on load, out = |scale * X|^2 (the fused epilogue of BASELINE config 2)
+template <typename T, int LOG2N, int UNROLL, bool HANNPOWER>
 __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 {
     constexpr int N = 1 << LOG2N;
@@ -87,6 +89,9 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 #pragma unroll
         for (int r = 0; r < K; ++r) w[s][r] = a.tw[((li * K + r) & (h - 1)) << s];
     }
+    T win[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) win[r] = HANNPOWER ? a.win[li * K + r] : (T)1;
     // bit-reversed position of each element, relative to the wave's block
     int pos[K];
 #pragma unroll
@@ -114,6 +119,10 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
                 x[u][0] = C{(T)__longlong_as_double(((long long)v.y << 32) | v.x),
                             (T)__longlong_as_double(((long long)v.w << 32) | v.z)};
             }
+            if constexpr (HANNPOWER) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) { x[u][r].x *= win[r]; x[u][r].y *= win[r]; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -133,18 +142,21 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
             const int64_t base = (b0 + u) << 6;
             if (base + lane < a.units) {
 #pragma unroll
-                for (int r = 0; r < K; ++r)
-                    st_stream(a.out + base * K + pos[r], C{x[u][r].x * a.scale, x[u][r].y * a.scale});
+                for (int r = 0; r < K; ++r) {
+                    const T re = x[u][r].x * a.scale, im = x[u][r].y * a.scale;
+                    if constexpr (HANNPOWER) st_stream(static_cast<T*>(a.out) + base * K + pos[r], re * re + im * im);
+                    else st_stream(static_cast<C*>(a.out) + base * K + pos[r], C{re, im});
+                }
             }
         }
     }
 }
 
-template <typename T, int LOG2N>
+template <typename T, int LOG2N, bool HANNPOWER>
 int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int UNROLL = 4;
-    auto kern = fft_wave_kernel<T, LOG2N, UNROLL>;
+    auto kern = fft_wave_kernel<T, LOG2N, UNROLL, HANNPOWER>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
@@ -162,12 +174,13 @@ int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 
 // complex64: 4..128 points, complex128: 2..64 points
 template <typename T>
-int launch_wave_any(int log2n, const WaveArgs<T>& a, hipStream_t s)
+int launch_wave_any(int log2n, bool hann_power, const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int MAXLOG = sizeof(T) == 4 ? 7 : 6;
     constexpr int MINLOG = sizeof(T) == 4 ? 2 : 1;
     switch (log2n) {
-#define MFFT_W(L) case L: if constexpr (L >= MINLOG && L <= MAXLOG) return launch_wave_one<T, L>(a, s); else break;
+#define MFFT_W(L) case L: if constexpr (L >= MINLOG && L <= MAXLOG) \
+        return hann_power ? launch_wave_one<T, L, true>(a, s) : launch_wave_one<T, L, false>(a, s); else break;
         MFFT_W(1) MFFT_W(2) MFFT_W(3) MFFT_W(4) MFFT_W(5) MFFT_W(6) MFFT_W(7)
 #undef MFFT_W
     }

@@ -44,7 +44,7 @@ def test_plain_fft_pow2(fa, dtype, log2n):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("n", [64, 1024, 4096])
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 1024, 4096])
 def test_hann_power_fused(fa, dtype, n):
     batch = 33
     cdt = np.complex64 if dtype == 0 else np.complex128
@@ -54,7 +54,7 @@ def test_hann_power_fused(fa, dtype, n):
         S = p.exec_host(x, scale=dt)
     assert S.dtype == (np.float32 if dtype == 0 else np.float64)
     _, ref = so.windowed_power(x, use_hann=True, dt=dt, engine="numpy")
-    assert rel_l2(S, ref) < 2 * TOL[dtype]      # |.|^2 doubles the relative error of F
+    assert rel_l2(S, ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -68,7 +68,7 @@ def test_zero_pad_window_demod_stats(fa, dtype):
     with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags) as p:
         S, stats = p.exec_host(x, scale=dt, mu=mu, t0=0.0, dt=dt)
     _, ref = so.windowed_power(x, n=n, use_hann=True, dt=dt, engine="numpy", mu=mu, times=times)
-    assert rel_l2(S, ref) < 2 * TOL[dtype]
+    assert rel_l2(S, ref) < TOL[dtype]
     f = np.fft.fftfreq(n) * n
     tol = 1e-5 if dtype == 0 else 1e-11
     np.testing.assert_allclose(stats[:, 0], ref.max(axis=1), rtol=tol)
