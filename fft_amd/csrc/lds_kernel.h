@@ -648,7 +648,10 @@ template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices
 template <> struct SizeCfg<11> { static constexpr int P = 16; using RD = Radices<8, 16, 16, 1>; };
 template <> struct SizeCfg<12> { static constexpr int P = 16; using RD = Radices<16, 16, 16, 1>; };
 template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices<2, 16, 16, 16>; };
-template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices<4, 16, 16, 16>; };
+#ifndef MFFT_P16384
+#define MFFT_P16384 16
+#endif
+template <> struct SizeCfg<14> { static constexpr int P = MFFT_P16384; using RD = Radices<4, 16, 16, 16>; };
 
 constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_write_b64 scatter
 
