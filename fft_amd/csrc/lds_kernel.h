@@ -41,6 +41,9 @@
 #ifndef MFFT_FAST_BUF
 #define MFFT_FAST_BUF 0      // tuning aid: 1 = buffer-resource accesses (scalar offsets) in the plain / hann+power variants
 #endif
+#ifndef MFFT_WIN_BUF_FROM
+#define MFFT_WIN_BUF_FROM 16384
+#endif
 #ifndef MFFT_PREFETCH
 #define MFFT_PREFETCH 0      // 1 = wave-private fast variants load the next signal before transforming the current one
 #endif
@@ -57,7 +60,7 @@
 namespace mfft {
 
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
-enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2 };
+enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2, WIN_BUF = 3 };
 
 // Waves per SIMD the register allocator must leave room for (1 = no constraint).  The 8192-point
 // complex64 kernel (512 threads, 68 KiB of LDS) fits two workgroups per CU only at <= 128 VGPRs;
@@ -323,7 +326,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int TWN = twreg_count<RD, TX, P>();
     constexpr int TWSRC = tw_source<RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
-    constexpr int WINSRC = MFFT_WIN_SRC;
+    // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
+    // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
+    // offsets instead, 2.4 -> 3.5 TB/s; at 8192 points the register copy is still 5-7 % faster
+    constexpr int WINSRC = (MFFT_WIN_SRC == WIN_REG && N >= MFFT_WIN_BUF_FROM) ? WIN_BUF : MFFT_WIN_SRC;
     static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -412,6 +418,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 for (int e = 0; e < P; ++e) {
                     T w;
                     if constexpr (WINSRC == WIN_REG) w = wreg[e];
+                    else if constexpr (WINSRC == WIN_BUF) w = buf_ld<T>(make_rsrc(a.win, (uint32_t)N * sizeof(T)), (uint32_t)t * sizeof(T), TX * e * sizeof(T));
                     else if constexpr (WINSRC == WIN_LDS) w = winl[t + TX * e];
                     else w = a.win[t + TX * e];
                     v[e].x *= w;

@@ -44,9 +44,9 @@ def test_plain_fft_pow2(fa, dtype, log2n):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 1024, 4096])
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 1024, 4096, 8192, 16384])
 def test_hann_power_fused(fa, dtype, n):
-    batch = 33
+    batch = 33 if n <= 4096 else 5
     cdt = np.complex64 if dtype == 0 else np.complex128
     x = _rand((batch, n), 3 * n + dtype, cdt)
     dt = 0.01
