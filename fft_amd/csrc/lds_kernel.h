@@ -662,8 +662,16 @@ template <> struct SizeCfg<14> { static constexpr int P = MFFT_P16384; using RD 
 
 constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_write_b64 scatter
 
-template <int LOG2N> struct BlockCfg {
-    static constexpr int TX = (1 << LOG2N) / SizeCfg<LOG2N>::P;
+// Points per thread of a variant.  The runtime prologue / epilogue variants of the 16384-point kernel
+// hold 32 points per thread in a 512-thread workgroup: at 16 points x 1024 threads (128 VGPRs) they
+// spill, 3.0 TB/s against 3.9; the fast variants measured the other way round (4.5 against 3.8).
+template <int LOG2N, int VAR> constexpr int points_per_thread()
+{
+    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeCfg<LOG2N>::P;
+}
+
+template <int LOG2N, int VAR = V_PLAIN> struct BlockCfg {
+    static constexpr int TX = (1 << LOG2N) / points_per_thread<LOG2N, VAR>();
     static constexpr int BLOCK = TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN;
 };
 
@@ -671,10 +679,11 @@ template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_f
 {
     using SC = SizeCfg<LOG2N>;
     constexpr int N = 1 << LOG2N;
-    constexpr int TX = BlockCfg<LOG2N>::TX, BLOCK = BlockCfg<LOG2N>::BLOCK;
+    constexpr int TX = BlockCfg<LOG2N, VAR>::TX, BLOCK = BlockCfg<LOG2N, VAR>::BLOCK;
     constexpr int SLOTS = BLOCK / TX;
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>(N - 1) + 1 + 1) / 2) * 2;
-    return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>) + table_lds_bytes<T, typename SC::RD, TX, SC::P, VAR>();
+    return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>) +
+           table_lds_bytes<T, typename SC::RD, TX, points_per_thread<LOG2N, VAR>(), VAR>();
 }
 
 // persistent grid: resident workgroups per CU (queried once per kernel) x CUs, capped by the work
@@ -685,10 +694,10 @@ template <typename T, int LOG2N, int VAR>
 int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
 {
     using SC = SizeCfg<LOG2N>;
-    constexpr int BLOCK = BlockCfg<LOG2N>::BLOCK;
-    constexpr int SLOTS = BLOCK / BlockCfg<LOG2N>::TX;
+    constexpr int BLOCK = BlockCfg<LOG2N, VAR>::BLOCK;
+    constexpr int SLOTS = BLOCK / BlockCfg<LOG2N, VAR>::TX;
     constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0;
-    auto kern = fft_lds_kernel<T, SC::P, typename SC::RD, kPadShift, BLOCK, VAR>;
+    auto kern = fft_lds_kernel<T, points_per_thread<LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
