@@ -141,8 +141,24 @@ __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>
     for (int e = 0; e < P; ++e) v[e] = lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)];
 }
 
+#ifndef MFFT_TILE_OCC
+#define MFFT_TILE_OCC 1      // 1 = hold the plain modes at the VGPR count that lets two workgroups share a CU
+#endif
+// Waves per SIMD the register allocator must leave room for.  A workgroup of B threads is B/256
+// waves per SIMD; two of them fit a CU's LDS for every tile shape, but only if each wave stays at
+// 512 / (B/128) VGPRs.  Several plain modes compiled to just above that (130-154 against 128), i.e.
+// to one resident workgroup and no overlap between its load, compute and store phases.
+// Measured: +1..4 % on every complex64 length; complex128 (whose spills under the cap reach 40-280
+// bytes per lane) lost up to 11 %, so it keeps the compiler's own allocation.
+template <typename T, int BLOCK, int MODE> constexpr int tile_min_waves()
+{
+    constexpr bool plain = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
+    return (MFFT_TILE_OCC != 0 && sizeof(T) == 4 && plain && BLOCK <= 512) ? BLOCK / 128 : 1;
+}
+
 template <typename T, int LOG2G, int LOG2C, int MODE>
-__global__ void __launch_bounds__((TileCfg<LOG2G>::TX) << LOG2C) fft_tile_kernel(const TArgs<T> a)
+__global__ void __launch_bounds__(((TileCfg<LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<LOG2G>::TX) << LOG2C), MODE>()))
+fft_tile_kernel(const TArgs<T> a)
 {
     constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN);
     using C_ = cx<T>;
