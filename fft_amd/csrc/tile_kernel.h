@@ -325,6 +325,10 @@ fft_tile_kernel(const TArgs<T> a)
             // last pass of a column-batched transform with the four-step twiddle folded in:
             // row k = (j >> log2_w) + q*(NS >> log2_w), column cc = tw_c0 + (j & (W-1));
             // exponent k*cc = base + q*step, built like the inter-pass twiddle above
+            // (keep the table reads below the column DFT: hoisted above it they hold ~50 registers
+            // through the butterflies and cost the second resident workgroup)
+#pragma unroll
+            for (int e = 0; e < P; ++e) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
             const uint64_t cc = (uint64_t)(a.tw_c0 + (j & ((int64_t(1) << a.log2_w) - 1)));
             const uint64_t nsr = (uint64_t)(a.NS >> a.log2_w);
             const uint64_t kb = (((uint64_t)(j >> a.log2_w) + (uint64_t)t * nsr) * cc) & a.fs_mask;
