@@ -485,6 +485,7 @@ struct Pow2Engine {
     void* stage_out = nullptr;          // caller layout is segmented (allocated on first use)
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
+    int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
     int narrow = 0;                     // tile width class (TileCols)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
@@ -618,12 +619,27 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         if (rc) return rc;
         bytes += (lo_n + hi_n) * 2 * (int64_t)sizeof(double);
     }
-    const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
     // measured on MI355X (2^15..2^24 points, 128 MiB and 1 GiB per launch): streaming accesses
     // win 1-15 % on the three-pass lengths (most where the transform fits the Infinity Cache)
     // and are a wash or a small loss on the two-pass ones
+    const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
     tile_nt = (passes.size() >= 3 || inner > 1) ? 3 : 0;
-    if (const char* env = getenv("MFFT_TILE_NT")) tile_nt = atoi(env) & 3;   // tuning aid
+    // three passes over 96..384 MiB of data (about the Infinity Cache's size): passes 1 and 2 keep
+    // their stores temporal so that the next pass finds them on chip (2^24 points: complex64
+    // 151 -> 147 us, complex128 297 -> 270 us); below that range every policy measures the same,
+    // above it fully streaming passes are 3 % faster
+    if (passes.size() == 3 && inner == 1 && wbytes >= (size_t(96) << 20) && wbytes <= (size_t(384) << 20)) {
+        tile_nt_pass[0] = 1;
+        tile_nt_pass[1] = 1;
+    }
+    if (const char* env = getenv("MFFT_TILE_NT")) {                            // tuning aid
+        tile_nt = atoi(env) & 3;
+        tile_nt_pass[0] = tile_nt_pass[1] = -1;
+    }
+    if (const char* env = getenv("MFFT_TILE_NT_PASS")) {                       // tuning aid: "3,0,2"
+        int k = 0;
+        for (const char* c = env; *c && k < 4; ++c) if (*c >= '0' && *c <= '3') tile_nt_pass[k++] = *c - '0';
+    }
     const int nwork = passes.size() > 2 ? 2 : (passes.size() > 1 ? 1 : 0);
     for (int i = 0; i < nwork; ++i) {
         MFFT_HIP(hipMalloc(&work[i], wbytes));
@@ -751,7 +767,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.narrow = narrow;
         a.batch = nb;
         a.lb = gp.lb;
-        a.nt = tile_nt;
+        a.nt = (p < 4 && tile_nt_pass[p] >= 0) ? tile_nt_pass[p] : tile_nt;
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
