@@ -619,22 +619,19 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         if (rc) return rc;
         bytes += (lo_n + hi_n) * 2 * (int64_t)sizeof(double);
     }
-    // measured on MI355X (2^15..2^24 points, 128 MiB and 1 GiB per launch): streaming accesses
-    // win 1-15 % on the three-pass lengths (most where the transform fits the Infinity Cache)
-    // and are a wash or a small loss on the two-pass ones
     const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
-    tile_nt = (passes.size() >= 3 || inner > 1) ? 3 : 0;
-    // three passes over 96..384 MiB of data (about the Infinity Cache's size): passes 1 and 2 keep
-    // their stores temporal so that the next pass finds them on chip (2^24 points: complex64
-    // 151 -> 147 us, complex128 297 -> 270 us); below that range every policy measures the same,
-    // above it fully streaming passes are 3 % faster
-    if (passes.size() == 3 && inner == 1 && wbytes >= (size_t(96) << 20) && wbytes <= (size_t(384) << 20)) {
-        tile_nt_pass[0] = 1;
-        tile_nt_pass[1] = 1;
-    }
+    // Cache policy of the plain tile passes, measured on MI355X with every per-pass combination
+    // (2^16..2^24 points, 16 MiB..1 GiB per launch, both precisions): up to about the Infinity
+    // Cache's size the best or tied-best choice is streaming loads everywhere, temporal stores in
+    // every pass but the last (the next pass finds its input on chip) and streaming stores in the
+    // last one -- 4..16 % over plain accesses on two-pass lengths, 3..9 % over fully streaming
+    // passes on three-pass ones; beyond that size fully streaming passes win by 1..5 %.
+    tile_nt = 3;
+    if (inner == 1 && wbytes <= (size_t(384) << 20))
+        for (size_t p = 0; p + 1 < passes.size() && p < 4; ++p) tile_nt_pass[p] = 1;
     if (const char* env = getenv("MFFT_TILE_NT")) {                            // tuning aid
         tile_nt = atoi(env) & 3;
-        tile_nt_pass[0] = tile_nt_pass[1] = -1;
+        for (int& v : tile_nt_pass) v = -1;
     }
     if (const char* env = getenv("MFFT_TILE_NT_PASS")) {                       // tuning aid: "3,0,2"
         int k = 0;
