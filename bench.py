@@ -232,6 +232,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sync_all()      # the first barrier sets up the communicator: keep that out of the settled phase
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < args.settle:
         for _ in range(100):
