@@ -1084,51 +1084,69 @@ static int plan_exec(Plan* p, const void* d_in, void* d_out, double scale, doubl
 // the batch is cut into slabs that a few threads copy through two pinned buffers per direction
 // while the previous slab is on the bus and in the kernels.
 // ---------------------------------------------------------------------------
+void stream_copy(void* dst, const void* src, size_t bytes);   // hostcopy.cpp
+
 class CopyPool {
 public:
-    static CopyPool& get()
+    // one pool per direction: uploads and downloads are copied concurrently
+    static CopyPool& in()
     {
         static CopyPool* pool = new CopyPool;      // never destroyed: its threads outlive main()
         return *pool;
     }
-    void copy(void* dst, const void* src, size_t bytes)
+    static CopyPool& out()
     {
-        const int parts = bytes < (size_t(1) << 20) ? 1 : nthreads_;
-        if (parts <= 1) { memcpy(dst, src, bytes); return; }
-        std::unique_lock<std::mutex> lk(mu_);
-        idle_.wait(lk, [&] { return pending_ == 0; });        // one job at a time
-        dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes;
-        next_ = 0; parts_ = parts; pending_ = parts;
-        ++generation_;
-        work_.notify_all();
-        idle_.wait(lk, [&] { return pending_ == 0; });
+        static CopyPool* pool = new CopyPool;
+        return *pool;
     }
+    // Starts a copy on the pool's threads and returns its ticket; wait(ticket) returns once that
+    // copy is complete.  Jobs of concurrent callers run one after the other.
+    uint64_t start(void* dst, const void* src, size_t bytes)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_.wait(lk, [&] { return pending_ == 0; });
+        dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes;
+        parts_ = bytes < (size_t(1) << 20) ? 1 : nthreads_;
+        next_ = 0; pending_ = parts_;
+        const uint64_t ticket = ++generation_;
+        work_.notify_all();
+        return ticket;
+    }
+    void wait(uint64_t ticket)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        idle_.wait(lk, [&] { return done_ >= ticket; });
+    }
+    void copy(void* dst, const void* src, size_t bytes) { wait(start(dst, src, bytes)); }
 
 private:
     CopyPool()
     {
-        int n = 8;                                  // measured on the GPU box: 3 -> 6 -> 12 threads = 29 -> 25 -> 22 ms per GiB moved
+        int n = 8;                                  // measured on the GPU box: 4 -> 8 -> 12 threads = 27 -> 21 -> 21 ms per GiB moved
         if (const char* env = getenv("MFFT_COPY_THREADS")) n = atoi(env);
         nthreads_ = n < 1 ? 1 : (n > 32 ? 32 : n);
+        if (const char* env = getenv("MFFT_COPY_STREAM")) stream_ = atoi(env) != 0;   // tuning aid
         for (int i = 0; i < nthreads_; ++i) std::thread([this] { loop(); }).detach();
     }
     void loop()
     {
-        uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            work_.wait(lk, [&] { return generation_ != seen && next_ < parts_; });
+            work_.wait(lk, [&] { return next_ < parts_; });
             while (next_ < parts_) {
                 const int part = next_++;
                 const size_t per = (bytes_ + (size_t)parts_ - 1) / (size_t)parts_;
                 const size_t lo = (size_t)part * per, hi = lo + per > bytes_ ? bytes_ : lo + per;
                 char* d = dst_; const char* sr = src_;
+                const uint64_t gen = generation_;
                 lk.unlock();
-                if (lo < hi) memcpy(d + lo, sr + lo, hi - lo);
+                if (lo < hi) {
+                    if (stream_) stream_copy(d + lo, sr + lo, hi - lo);
+                    else memcpy(d + lo, sr + lo, hi - lo);
+                }
                 lk.lock();
-                if (--pending_ == 0) idle_.notify_all();
+                if (--pending_ == 0) { done_ = gen; idle_.notify_all(); }
             }
-            seen = generation_;
         }
     }
     std::mutex mu_;
@@ -1136,7 +1154,8 @@ private:
     char* dst_ = nullptr; const char* src_ = nullptr;
     size_t bytes_ = 0;
     int next_ = 0, parts_ = 0, pending_ = 0, nthreads_ = 1;
-    uint64_t generation_ = 0;
+    uint64_t generation_ = 0, done_ = 0;
+    bool stream_ = true;
 };
 
 static int pipe_prepare(Plan* p, size_t in_row, size_t out_row)
@@ -1159,46 +1178,61 @@ static int pipe_prepare(Plan* p, size_t in_row, size_t out_row)
     return MFFT_OK;
 }
 
-// h_in -> (threads) pinned -> H2D -> kernels -> D2H -> pinned -> (threads) h_out, two slabs in flight
+// h_in -> (threads) pinned -> H2D -> kernels -> D2H -> pinned -> (threads) h_out.  Two slabs are in
+// flight per direction; the download copies run on their own threads, concurrently with the upload
+// copy of the following slab (a fresh output array costs page faults on top of the copy: measured
+// 15 ms per 512 MiB against 8 ms for the upload side, one after the other before).
 static int exec_host_pipelined(Plan* p, const char* h_in, char* h_out, size_t in_row, size_t out_row, double scale,
                                double mu, double t0, double dt)
 {
     int rc = pipe_prepare(p, in_row, out_row);
     if (rc) return rc;
-    CopyPool& pool = CopyPool::get();
+    CopyPool& pin = CopyPool::in();
+    CopyPool& pout = CopyPool::out();
     const int64_t slab = p->pipe_slab, batch = p->batch;
     const int64_t nslab = (batch + slab - 1) / slab;
     char* d_in = static_cast<char*>(p->d_in);
     char* d_out = static_cast<char*>(p->d_out);
+    uint64_t out_ticket[2] = {0, 0};                   // download copy still reading pin_out[q]
+    const auto drain = [&] { pout.wait(out_ticket[0]); pout.wait(out_ticket[1]); };
+    // no return while a download copy still writes into the caller's array
+#define PIPE_HIP(expr)                                                              \
+    do {                                                                            \
+        const hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) { drain(); return hip_fail(e_, #expr, __FILE__, __LINE__); } \
+    } while (0)
     for (int64_t k = 0; k < nslab; ++k) {
         const int q = (int)(k & 1);
         const int64_t b0 = k * slab, cnt = batch - b0 < slab ? batch - b0 : slab;
-        if (k >= 2) MFFT_HIP(hipEventSynchronize(p->ev_in[q]));             // pin_in[q] has left for the device
-        pool.copy(p->pin_in[q], h_in + (size_t)b0 * in_row, (size_t)cnt * in_row);
-        MFFT_HIP(hipMemcpyAsync(d_in + (size_t)b0 * in_row, p->pin_in[q], (size_t)cnt * in_row, hipMemcpyHostToDevice, p->s_run));
-        MFFT_HIP(hipEventRecord(p->ev_in[q], p->s_run));
+        if (k >= 2) PIPE_HIP(hipEventSynchronize(p->ev_in[q]));             // pin_in[q] has left for the device
+        pin.copy(p->pin_in[q], h_in + (size_t)b0 * in_row, (size_t)cnt * in_row);
+        PIPE_HIP(hipMemcpyAsync(d_in + (size_t)b0 * in_row, p->pin_in[q], (size_t)cnt * in_row, hipMemcpyHostToDevice, p->s_run));
+        PIPE_HIP(hipEventRecord(p->ev_in[q], p->s_run));
         rc = plan_exec(p, d_in + (size_t)b0 * in_row, d_out + (size_t)b0 * out_row, scale, mu, t0, dt,
                        p->d_stats ? p->d_stats + 3 * b0 : nullptr, p->s_run, cnt, k == 0);
-        if (rc) { (void)hipStreamSynchronize(p->s_run); (void)hipStreamSynchronize(p->s_out); return rc; }
+        if (rc) { (void)hipStreamSynchronize(p->s_run); (void)hipStreamSynchronize(p->s_out); drain(); return rc; }
         if (h_out) {
-            MFFT_HIP(hipEventRecord(p->ev_run[q], p->s_run));
-            MFFT_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[q], 0));
-            MFFT_HIP(hipMemcpyAsync(p->pin_out[q], d_out + (size_t)b0 * out_row, (size_t)cnt * out_row, hipMemcpyDeviceToHost, p->s_out));
-            MFFT_HIP(hipEventRecord(p->ev_out[q], p->s_out));
-            if (k >= 1) {                                                    // drain the previous slab meanwhile
-                MFFT_HIP(hipEventSynchronize(p->ev_out[q ^ 1]));
-                pool.copy(h_out + (size_t)(b0 - slab) * out_row, p->pin_out[q ^ 1], (size_t)slab * out_row);
+            PIPE_HIP(hipEventRecord(p->ev_run[q], p->s_run));
+            PIPE_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[q], 0));
+            pout.wait(out_ticket[q]);                                        // slab k-2 has left pin_out[q]
+            PIPE_HIP(hipMemcpyAsync(p->pin_out[q], d_out + (size_t)b0 * out_row, (size_t)cnt * out_row, hipMemcpyDeviceToHost, p->s_out));
+            PIPE_HIP(hipEventRecord(p->ev_out[q], p->s_out));
+            if (k >= 1) {                                                    // previous slab: start its download copy
+                PIPE_HIP(hipEventSynchronize(p->ev_out[q ^ 1]));
+                out_ticket[q ^ 1] = pout.start(h_out + (size_t)(b0 - slab) * out_row, p->pin_out[q ^ 1], (size_t)slab * out_row);
             }
         }
     }
     if (h_out) {
         const int q = (int)((nslab - 1) & 1);
         const int64_t b0 = (nslab - 1) * slab;
-        MFFT_HIP(hipEventSynchronize(p->ev_out[q]));
-        pool.copy(h_out + (size_t)b0 * out_row, p->pin_out[q], (size_t)(batch - b0) * out_row);
+        PIPE_HIP(hipEventSynchronize(p->ev_out[q]));
+        out_ticket[q] = pout.start(h_out + (size_t)b0 * out_row, p->pin_out[q], (size_t)(batch - b0) * out_row);
+        drain();
     }
-    MFFT_HIP(hipStreamSynchronize(p->s_run));
+    PIPE_HIP(hipStreamSynchronize(p->s_run));
     return MFFT_OK;
+#undef PIPE_HIP
 }
 
 // RAII: make the plan's device current for the duration of a call

@@ -162,3 +162,37 @@ def test_pipelined_host_path(fa, monkeypatch):
             if flags & fa.STATS:
                 st = p.exec_host(x, scale=0.5, stats_only=True)
                 assert np.allclose(st, ref[1], rtol=1e-12)
+
+
+def test_pipelined_host_path_concurrent_callers(fa, monkeypatch):
+    """Several threads run pipelined host transfers at once, each on its own plan: the copy threads
+    are shared (one job at a time per direction), so every caller must still get exactly its own
+    result -- bit for bit the single-copy path's."""
+    import threading
+    rng = np.random.default_rng(77)
+    shapes = [(1024, 8192 + 5, 0), (2048, 4096 + 3, 0), (512, 9000, 1), (1000, 8200, 0)]
+    inputs, refs, plans = [], [], []
+    monkeypatch.setenv("MFFT_NO_PIPELINE", "1")
+    for n, batch, dtype in shapes:
+        cdt = np.complex64 if dtype == 0 else np.complex128
+        x = (rng.standard_normal((batch, n), dtype=np.float32)
+             + 1j * rng.standard_normal((batch, n), dtype=np.float32)).astype(cdt)
+        p = fa.Plan(n, batch=batch, dtype=dtype)
+        inputs.append(x); plans.append(p); refs.append(p.exec_host(x, scale=2.0))
+    monkeypatch.delenv("MFFT_NO_PIPELINE")
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got = plans[i].exec_host(inputs[i], scale=2.0)
+                if not np.array_equal(got, refs[i]):
+                    errors.append(f"caller {i}: result differs")
+        except Exception as e:                                            # noqa: BLE001
+            errors.append(f"caller {i}: {e!r}")
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(shapes))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    [p.destroy() for p in plans]
+    assert not errors, errors
