@@ -1,0 +1,312 @@
+// Element-wise and reduction kernels around the transforms: window/demodulation/chirp tables,
+// Bluestein filter, max-normalisation, transposes and block copies of the multi-GPU routes, the
+// normal equations of the line fit, the return-amplitude generator, the local-maxima scan and the
+// one-point "transform".  Included by plan.hip only.
+#pragma once
+#include "common.h"
+
+namespace mfft {
+
+
+// pre[j] = win[j] * exp(+i*mu*(t0 + j*dt)) * extra[j]   (win / extra optional)
+template <typename T>
+__global__ void premul_kernel(cx<T>* pre, const T* win, const cx<T>* extra, int n, double mu, double t0,
+                              double dt, int demod)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double re = 1.0, im = 0.0;
+    if (demod) {
+        double s, c;
+        sincos(mu * (t0 + (double)j * dt), &s, &c);
+        re = c;
+        im = s;
+    }
+    if (win) { re *= (double)win[j]; im *= (double)win[j]; }
+    if (extra) {
+        const double er = (double)extra[j].x, ei = (double)extra[j].y;
+        const double r2 = re * er - im * ei, i2 = re * ei + im * er;
+        re = r2;
+        im = i2;
+    }
+    pre[j] = cx<T>{(T)re, (T)im};
+}
+
+// chirp[j] = exp(-i*pi*j^2/n), j < n: j^2 is reduced mod 2n in integers (j < 2^31, so j^2 fits 64
+// bits), then to the nearest quarter turn, and the remaining angle |x| <= 1/4 (in units of pi) goes
+// through sincospi -- the phase error stays at the 1e-16 level for every j, as the long-double host
+// tables have it, at a fraction of their cost (the apps' largest length, 1.28e8 points: 12 s of host
+// sinl/cosl).
+template <typename T>
+__global__ void chirp_kernel(cx<T>* chirp, int64_t n)
+{
+    const uint64_t N = 2 * (uint64_t)n;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = ((uint64_t)j * (uint64_t)j) % N;
+        const uint64_t k4 = 4 * k;
+        const uint64_t q = (k4 + N / 2) / N;                          // nearest quarter turn
+        const int64_t rem = (int64_t)k4 - (int64_t)(q * N);           // |rem| <= N/2
+        double sa, ca;
+        sincospi((double)rem / (double)(2 * N), &sa, &ca);            // angle = 2*pi*rem/(4N)
+        double c, sn;
+        switch (q & 3) {
+        case 0: c = ca; sn = sa; break;
+        case 1: c = -sa; sn = ca; break;
+        case 2: c = -ca; sn = -sa; break;
+        default: c = sa; sn = -ca; break;
+        }
+        chirp[j] = cx<T>{(T)c, (T)(-sn)};
+    }
+}
+
+// Bluestein filter b[d] = conj(chirp[|d|]) for -n_in < d < n, wrapped into m points, zero elsewhere
+template <typename T>
+__global__ void chirp_filter_kernel(const cx<T>* chirp, cx<T>* b, int64_t n, int64_t n_in, int64_t m)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        cx<T> v{0, 0};
+        if (i < n) v = cx<T>{chirp[i].x, -chirp[i].y};
+        else if (m - i < n_in) v = cx<T>{chirp[m - i].x, -chirp[m - i].y};
+        b[i] = v;
+    }
+}
+
+template <typename T>
+__global__ void normalize_kernel(const T* in, T* out, int64_t count, const double* d_max)
+{
+    const double m = *d_max;
+    const T den = (T)(m > 0.0 ? m : 1.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] / den;
+}
+
+// out[b][c][r] = in[b][r][c], 32x32 tiles through LDS (33-wide rows: no bank conflicts)
+template <typename T>
+__global__ void transpose_kernel(const cx<T>* in, cx<T>* out, int64_t rows, int64_t cols)
+{
+    __shared__ cx<T> tile[32][33];
+    const int64_t b = blockIdx.z;
+    const cx<T>* src = in + b * rows * cols;
+    cx<T>* dst = out + b * rows * cols;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[i][tx] = src[r * cols + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[c * rows + r] = tile[tx][i];
+    }
+}
+
+// dense[b][j] <-> seg[b*batch_stride + (j/seg)*seg_stride + j%seg] for `count` elements per signal of
+// type E (to_dense = gather, else scatter): stages the rare combinations of a segmented layout
+// with a runtime prologue / epilogue, which the LDS-resident general variants do not address
+template <typename E>
+__global__ void seg_copy_kernel(const E* src, E* dst, int64_t batch, int64_t count, int64_t batch_stride,
+                                int64_t seg, int64_t seg_stride, int to_dense)
+{
+    const int64_t total = batch * count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / count, j = i - b * count;
+        const int64_t at = b * batch_stride + seg_index(j, seg, seg_stride);
+        if (to_dense) dst[i] = src[at];
+        else dst[at] = src[i];
+    }
+}
+
+// out[b][a][:] = in[a][b][:] for an (A, B, W) array of complex elements: one row of W
+// contiguous elements per loop trip, copied 16 bytes per lane where W allows
+template <typename T>
+__global__ void swap_axes_kernel(const cx<T>* in, cx<T>* out, int64_t A, int64_t B, int64_t W)
+{
+    constexpr int PER16 = 16 / (int)sizeof(cx<T>);            // elements per 16-byte unit
+    const int64_t rows = A * B;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int64_t a = row / B, b = row - a * B;
+        const cx<T>* src = in + row * W;
+        cx<T>* dst = out + (b * A + a) * W;
+        if (W % PER16 == 0) {
+            using V4 = float __attribute__((ext_vector_type(4)));
+            const V4* s4 = reinterpret_cast<const V4*>(src);
+            V4* d4 = reinterpret_cast<V4*>(dst);
+            const int64_t units = W / PER16;
+            for (int64_t u = threadIdx.x; u < units; u += blockDim.x)
+                __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + u), d4 + u);
+        } else {
+            for (int64_t u = threadIdx.x; u < W; u += blockDim.x) dst[u] = src[u];
+        }
+    }
+}
+
+// x[r][c] *= exp(-2*pi*i*(r0+r)*(c0+c)/n): two-level table product, tables built on the host
+template <typename T>
+__global__ void twiddle_tile_kernel(cx<T>* x, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
+                                    int64_t n, const cx<double>* lo, const cx<double>* hi, int lo_bits)
+{
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        // indices are reduced mod n first, and n <= 2^31, so the product fits 64 bits
+        const uint64_t prod = ((uint64_t)(r0 + r) % (uint64_t)n) * ((uint64_t)(c0 + c) % (uint64_t)n);
+        const int64_t k = (int64_t)(prod % (uint64_t)n);
+        const cx<double> a = lo[k & ((int64_t(1) << lo_bits) - 1)], b = hi[k >> lo_bits];
+        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        const cx<T> v = x[i];
+        x[i] = cx<T>{(T)((double)v.x * wr - (double)v.y * wi), (T)((double)v.x * wi + (double)v.y * wr)};
+    }
+}
+
+// Normal equations of the windowed line fit.  Columns b_a[j] = win[j] exp(-i E_a t_j), target
+// y[j] = x[j] win[j] exp(+i mu t_j).  blockIdx.y = a selects the row: out holds
+//   G[a][b] = sum_j conj(b_a[j]) b_b[j]   (2*m*m doubles, row-major, re/im interleaved)
+//   r[a]    = sum_j conj(b_a[j]) y[j]     (2*m doubles)
+//   yy      = sum_j |y[j]|^2              (1 double, accumulated by row 0)
+struct LsqArgs {
+    int m;            // all columns (rows of G): blockIdx.y
+    int c0, nc;       // this launch fills columns [c0, c0 + nc), nc <= 16
+    double mu;
+    double E[64];
+};
+
+__global__ void __launch_bounds__(256) lsq_normal_kernel(const cx<double>* x, const double* win, const double* times,
+                                                         int64_t n, LsqArgs a, double* out)
+{
+    const int row = blockIdx.y;
+    const int m = a.m, nc = a.nc;
+    double gr[16], gi[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) { gr[b] = 0.0; gi[b] = 0.0; }
+    double rr = 0.0, ri = 0.0, yy = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const double t = times[j];
+        const double w = win ? win[j] : 1.0;
+        double sa, ca;
+        sincos(a.E[row] * t, &sa, &ca);                // conj(b_a) = w (ca + i sa)
+        const double ar = w * ca, ai = w * sa;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            if (b < nc) {
+                double sb, cb;
+                sincos(a.E[a.c0 + b] * t, &sb, &cb);   // b_b = w (cb - i sb)
+                const double br = w * cb, bi = -w * sb;
+                gr[b] += ar * br - ai * bi;
+                gi[b] += ar * bi + ai * br;
+            }
+        }
+        if (a.c0 == 0) {                               // right-hand side and target energy: first launch only
+            cx<double> y = x[j];
+            y.x *= w; y.y *= w;
+            if (a.mu != 0.0) {
+                double sm, cm;
+                sincos(a.mu * t, &sm, &cm);
+                y = cx<double>{y.x * cm - y.y * sm, y.x * sm + y.y * cm};
+            }
+            rr += ar * y.x - ai * y.y;
+            ri += ar * y.y + ai * y.x;
+            yy += y.x * y.x + y.y * y.y;
+        }
+    }
+    // wave reduction, then one atomic per wave and value
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            if (b < nc) { gr[b] += __shfl_xor(gr[b], o, 64); gi[b] += __shfl_xor(gi[b], o, 64); }
+        }
+        rr += __shfl_xor(rr, o, 64);
+        ri += __shfl_xor(ri, o, 64);
+        yy += __shfl_xor(yy, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double* G = out + 2 * ((size_t)row * m + a.c0);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            if (b < nc) { atomicAdd(G + 2 * b, gr[b]); atomicAdd(G + 2 * b + 1, gi[b]); }
+        }
+        if (a.c0 == 0) {
+            double* r = out + 2 * (size_t)m * m + 2 * row;
+            atomicAdd(r, rr);
+            atomicAdd(r + 1, ri);
+            if (row == 0) atomicAdd(out + 2 * (size_t)m * m + 2 * m, yy);
+        }
+    }
+}
+
+// f[j] = sum_k vrow[k] * (exp(-i w[k] t_j / hbar) * c0[k]); the small per-block constants
+// travel in the kernel argument buffer
+struct AmpArgs {
+    int nk;
+    double hbar;
+    double w[32];
+    double c0[64];
+    double vrow[64];
+};
+
+__global__ void return_amplitude_kernel(cx<double>* out, int64_t n, const double* times, double t0, double dt,
+                                        const AmpArgs a)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const double t = times ? times[j] : t0 + (double)j * dt;
+        double fr = 0.0, fi = 0.0;
+        for (int k = 0; k < a.nk; ++k) {
+            double sn, cs;
+            sincos((a.w[k] * t) / a.hbar, &sn, &cs);
+            // tmp = exp(-i phi) * c0[k]
+            const double cr = a.c0[2 * k], ci = a.c0[2 * k + 1];
+            const double tr = cs * cr + sn * ci, ti = cs * ci - sn * cr;
+            // f += vrow[k] * tmp
+            const double vr = a.vrow[2 * k], vi = a.vrow[2 * k + 1];
+            fr += vr * tr - vi * ti;
+            fi += vr * ti + vi * tr;
+        }
+        out[j] = cx<double>{fr, fi};
+    }
+}
+
+// indices of interior local maxima (left strict, right weak), unordered, with a total count
+template <typename T>
+__global__ void local_maxima_kernel(const T* S, int64_t n, int64_t* idx, int64_t capacity,
+                                    unsigned long long* count)
+{
+    for (int64_t i = 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n - 1;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T c = S[i];
+        if (c > S[i - 1] && c >= S[i + 1]) {
+            const unsigned long long slot = atomicAdd(count, 1ULL);
+            if ((int64_t)slot < capacity) idx[slot] = i;
+        }
+    }
+}
+
+// out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and
+// epilogue of the general path applied to sample 0.
+template <typename T>
+__global__ void n1_kernel(const void* in, void* out, int64_t batch, int64_t in_stride, int real_in,
+                          const T* win, const cx<T>* pre, T scale, int conj, int power, double* stats)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    cx<T> x{0, 0};
+    if (real_in) x.x = static_cast<const T*>(in)[b * in_stride];
+    else x = static_cast<const cx<T>*>(in)[b * in_stride];
+    if (conj) x.y = -x.y;
+    if (win) { x.x *= win[0]; x.y *= win[0]; }
+    if (pre) x = cmul(x, pre[0]);
+    x.x *= scale;
+    x.y *= scale;
+    if (conj) x.y = -x.y;
+    if (power) {
+        const T s = x.x * x.x + x.y * x.y;
+        static_cast<T*>(out)[b] = s;
+        if (stats) { stats[3 * b] = (double)s; stats[3 * b + 1] = (double)s; stats[3 * b + 2] = 0.0; }
+    } else {
+        static_cast<cx<T>*>(out)[b] = x;
+    }
+}
+
+}  // namespace mfft
