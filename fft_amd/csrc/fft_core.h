@@ -116,6 +116,29 @@ template <typename T> MFFT_HD void dft16(cx<T>* v)
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
+// 32 points: two 16-point transforms of the even and odd inputs, combined with W32^k
+template <typename T> MFFT_HD void dft32(cx<T>* v)
+{
+    constexpr T c[16] = {(T)1.0L, (T)0.98078528040323044912618223613423903697L, (T)0.92387953251128675612818318939678828682L,
+                         (T)0.83146961230254523707878837761790575673L, (T)0.70710678118654752440084436210484903928L,
+                         (T)0.55557023301960222474283081394853287438L, (T)0.38268343236508977172845998403039886676L,
+                         (T)0.19509032201612826784828486847702224093L, (T)0.0L, (T)-0.19509032201612826784828486847702224093L,
+                         (T)-0.38268343236508977172845998403039886676L, (T)-0.55557023301960222474283081394853287438L,
+                         (T)-0.70710678118654752440084436210484903928L, (T)-0.83146961230254523707878837761790575673L,
+                         (T)-0.92387953251128675612818318939678828682L, (T)-0.98078528040323044912618223613423903697L};
+    cx<T> e[16] = {}, o[16] = {};
+    for (int i = 0; i < 16; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    dft16(e);
+    dft16(o);
+    for (int k = 0; k < 16; ++k) {
+        // W32^k = cos(2 pi k/32) - i sin(2 pi k/32), sin(2 pi k/32) = cos(2 pi (8-k)/32)
+        const T cs = c[k], sn = k <= 8 ? c[8 - k] : c[k - 8];
+        const cx<T> t{o[k].x * cs + o[k].y * sn, o[k].y * cs - o[k].x * sn};
+        v[k] = e[k] + t;
+        v[k + 16] = e[k] - t;
+    }
+}
+
 // Radix-R DFT of the R registers v[0], v[S], v[2S], ... (stride S), natural order.
 template <typename T, int R, int S> MFFT_HD void dft_strided(cx<T>* v)
 {
@@ -126,10 +149,10 @@ template <typename T, int R, int S> MFFT_HD void dft_strided(cx<T>* v)
     } else if constexpr (R == 4) {
         dft4(v[0], v[S], v[2 * S], v[3 * S]);
     } else {
-        cx<T> w[R];
+        cx<T> w[R] = {};
 #pragma unroll
         for (int i = 0; i < R; ++i) w[i] = v[i * S];
-        if constexpr (R == 8) dft8(w); else dft16(w);
+        if constexpr (R == 8) dft8(w); else if constexpr (R == 16) dft16(w); else dft32(w);
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i * S] = w[i];
     }

@@ -44,6 +44,9 @@
 #ifndef MFFT_WIN_BUF_FROM
 #define MFFT_WIN_BUF_FROM 16384
 #endif
+#ifndef MFFT_P8192
+#define MFFT_P8192 32        // points per thread of the 8192-point complex64 kernels (16 or 32)
+#endif
 #ifndef MFFT_PREFETCH
 #define MFFT_PREFETCH 0      // 1 = wave-private fast variants load the next signal before transforming the current one
 #endif
@@ -71,7 +74,7 @@ template <typename T, int N, int VAR> constexpr int min_waves_per_eu()
 #if MFFT_WAVES_PER_EU > 0
     return MFFT_WAVES_PER_EU;
 #else
-    return (sizeof(T) == 4 && N == 8192 && (VAR == V_PLAIN || VAR == V_SEG)) ? 4 : 1;
+    return (MFFT_P8192 == 16 && sizeof(T) == 4 && N == 8192 && (VAR == V_PLAIN || VAR == V_SEG)) ? 4 : 1;
 #endif
 }
 #define MFFT_LAUNCH_BOUNDS(B, T, N, VAR) __launch_bounds__(B, (min_waves_per_eu<T, N, VAR>()))
@@ -328,8 +331,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr bool TWREG = TWSRC == TW_REG;
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
     // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
-    // offsets instead, 2.4 -> 3.5 TB/s; at 8192 points the register copy is still 5-7 % faster
-    constexpr int WINSRC = (MFFT_WIN_SRC == WIN_REG && N >= MFFT_WIN_BUF_FROM) ? WIN_BUF : MFFT_WIN_SRC;
+    // offsets instead, 2.4 -> 3.5 TB/s; with 16 points per thread at 8192 the register copy is 5-7 % faster
+    // (likewise the 32-point-per-thread kernels: 32 more registers would halve their occupancy,
+    // 8192 points Hann + power 3.2 against 4.25 TB/s)
+    constexpr int WINSRC = (MFFT_WIN_SRC == WIN_REG && (N >= MFFT_WIN_BUF_FROM || P >= 32)) ? WIN_BUF : MFFT_WIN_SRC;
     static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -660,30 +665,42 @@ template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices
 #endif
 template <> struct SizeCfg<14> { static constexpr int P = MFFT_P16384; using RD = Radices<4, 16, 16, 16>; };
 
+// Per-precision exceptions.  8192 complex64 points: 32 points per thread and a radix-32 first pass.
+// With 16 points a signal needs a 512-thread workgroup and three LDS exchanges (2*16*16*16); the
+// same lengths measured 20-25 % slower in 512-thread workgroups than in 256-thread ones (4096
+// points: 4.2 against 5.5 TB/s), the price of barriers over eight waves.  32 points per thread is a
+// 256-thread workgroup, two exchanges (32*16*16) and 234-252 VGPRs, two workgroups per CU:
+// plain 4.25 -> 4.6 TB/s, windowed 3.7 -> 4.6, Hann + power 3.55 -> 4.25.  complex128 (128 KiB of
+// LDS per signal: one workgroup per CU either way) measured the same or slower and keeps 16.
+template <typename T, int LOG2N> struct SizeFor : SizeCfg<LOG2N> {};
+#if MFFT_P8192 == 32
+template <> struct SizeFor<float, 13> { static constexpr int P = 32; using RD = Radices<32, 16, 16, 1>; };
+#endif
+
 constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_write_b64 scatter
 
 // Points per thread of a variant.  The runtime prologue / epilogue variants of the 16384-point kernel
 // hold 32 points per thread in a 512-thread workgroup: at 16 points x 1024 threads (128 VGPRs) they
 // spill, 3.0 TB/s against 3.9; the fast variants measured the other way round (4.5 against 3.8).
-template <int LOG2N, int VAR> constexpr int points_per_thread()
+template <typename T, int LOG2N, int VAR> constexpr int points_per_thread()
 {
-    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeCfg<LOG2N>::P;
+    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeFor<T, LOG2N>::P;
 }
 
-template <int LOG2N, int VAR = V_PLAIN> struct BlockCfg {
-    static constexpr int TX = (1 << LOG2N) / points_per_thread<LOG2N, VAR>();
+template <typename T, int LOG2N, int VAR = V_PLAIN> struct BlockCfg {
+    static constexpr int TX = (1 << LOG2N) / points_per_thread<T, LOG2N, VAR>();
     static constexpr int BLOCK = TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN;
 };
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_for()
 {
-    using SC = SizeCfg<LOG2N>;
+    using SC = SizeFor<T, LOG2N>;
     constexpr int N = 1 << LOG2N;
-    constexpr int TX = BlockCfg<LOG2N, VAR>::TX, BLOCK = BlockCfg<LOG2N, VAR>::BLOCK;
+    constexpr int TX = BlockCfg<T, LOG2N, VAR>::TX, BLOCK = BlockCfg<T, LOG2N, VAR>::BLOCK;
     constexpr int SLOTS = BLOCK / TX;
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>(N - 1) + 1 + 1) / 2) * 2;
     return (size_t)SLOTS * LDS_ELEMS * sizeof(cx<T>) +
-           table_lds_bytes<T, typename SC::RD, TX, points_per_thread<LOG2N, VAR>(), VAR>();
+           table_lds_bytes<T, typename SC::RD, TX, points_per_thread<T, LOG2N, VAR>(), VAR>();
 }
 
 // persistent grid: resident workgroups per CU (queried once per kernel) x CUs, capped by the work
@@ -693,11 +710,11 @@ int pick_grid(int per_cu, int64_t groups);
 template <typename T, int LOG2N, int VAR>
 int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
 {
-    using SC = SizeCfg<LOG2N>;
-    constexpr int BLOCK = BlockCfg<LOG2N, VAR>::BLOCK;
-    constexpr int SLOTS = BLOCK / BlockCfg<LOG2N, VAR>::TX;
+    using SC = SizeFor<T, LOG2N>;
+    constexpr int BLOCK = BlockCfg<T, LOG2N, VAR>::BLOCK;
+    constexpr int SLOTS = BLOCK / BlockCfg<T, LOG2N, VAR>::TX;
     constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0;
-    auto kern = fft_lds_kernel<T, points_per_thread<LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
+    auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));

@@ -26,7 +26,7 @@ def _reference(x, n, flags, fa, scale, mu, t0, dt):
 
 
 LENGTHS = [  # (n, n_in): single-kernel, tile passes, chirp-z; with and without zero padding
-    (2, 2), (8, 5), (64, 64), (256, 100), (1024, 1024), (1024, 1), (4096, 4095), (8192, 8192), (16384, 3000),
+    (2, 2), (8, 5), (64, 64), (256, 100), (1024, 1024), (1024, 1), (4096, 4095), (8192, 8192), (8192, 5001), (16384, 3000),
     (1 << 15, 1 << 15), (1 << 16, 12345), (1 << 19, 1 << 19), (1 << 20, 70001),
     (3, 3), (17, 17), (1000, 1000), (1000, 37), (24016, 1501), (65537, 65537), (256032, 8001),
 ]
