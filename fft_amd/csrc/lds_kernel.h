@@ -150,12 +150,15 @@ template <int R0, int R1, int R2, int R3, bool SPLIT16 = (MFFT_TW16_SPLIT != 0)>
     static constexpr int n = R0 * R1 * R2 * R3;
 };
 
-// Entries of the twiddle table of pass s (s >= 1): (R-1) * NS, laid out [i-1][m].
+// Entries of the twiddle table of pass s (s >= 1): rows * NS, laid out [row][m].
 // Rows of a pass' twiddle table.  A radix-R butterfly needs w^1 .. w^(R-1) with w = W^(m);
 // a radix-16 pass stores only the six powers 1, 2, 3, 4, 8, 12 (rows 0..5) and forms
 // w^(4a+b) = w^(4a) * w^(b) on the fly: 2.5x fewer table entries, registers and loads for
-// nine extra complex multiplies per butterfly.
-constexpr int tw_rows(int r, bool split16) { return (r == 16 && split16) ? 6 : r - 1; }
+// nine extra complex multiplies per butterfly.  A radix-32 pass likewise stores 1, 2, 3 and
+// 4, 8, .. 28: ten rows instead of thirty-one.
+constexpr int tw_rows(int r, bool split16) { return (r >= 16 && split16) ? 2 + r / 4 : r - 1; }
+// power of w held by row `row` of a split table
+constexpr int tw_split_power(int row) { return row < 3 ? row + 1 : 4 * (row - 2); }
 template <class RD> constexpr int tw_pass_elems(int s) { return tw_rows(RD::r[s], RD::split16) * RD::ns(s); }
 template <class RD> constexpr int tw_pass_offset(int s)
 {
@@ -227,10 +230,9 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
 #pragma unroll
                 for (int i = 1; i < R; ++i) v[u + U * i] = cmul(v[u + U * i], row[i - 1]);
             } else {
-                // rows: w^1, w^2, w^3, w^4, w^8, w^12
+                // rows: w^1, w^2, w^3, w^4, w^8, w^12 (, .. w^28 for radix 32)
 #pragma unroll
-                for (int i = 1; i < 16; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
+                for (int i = 1; i < R; ++i) {
                     const int a4 = i >> 2, b = i & 3;
                     cx<T> w;
                     if (b == 0) w = row[2 + a4];                      // w^4, w^8, w^12
@@ -660,10 +662,18 @@ template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices
 template <> struct SizeCfg<11> { static constexpr int P = 16; using RD = Radices<8, 16, 16, 1>; };
 template <> struct SizeCfg<12> { static constexpr int P = 16; using RD = Radices<16, 16, 16, 1>; };
 template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices<2, 16, 16, 16>; };
+// 16384 points: 16 per thread in a 1024-thread workgroup (4*16*16*16), or 32 per thread in a
+// 512-thread one with radix-32 first and last passes (32*16*32).  One workgroup fits a CU either
+// way; the 32-point form measured slower where it matters: plain 4.13 against 4.44 TB/s, windowed
+// 2.4 against 3.9, Hann + power equal, power only 3.6 against 3.2.
 #ifndef MFFT_P16384
 #define MFFT_P16384 16
 #endif
-template <> struct SizeCfg<14> { static constexpr int P = MFFT_P16384; using RD = Radices<4, 16, 16, 16>; };
+#if MFFT_P16384 == 32
+template <> struct SizeCfg<14> { static constexpr int P = 32; using RD = Radices<32, 16, 32, 1>; };
+#else
+template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices<4, 16, 16, 16>; };
+#endif
 
 // Per-precision exceptions.  8192 complex64 points: 32 points per thread and a radix-32 first pass.
 // With 16 points a signal needs a 512-thread workgroup and three LDS exchanges (2*16*16*16); the
@@ -684,7 +694,7 @@ constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_wri
 // spill, 3.0 TB/s against 3.9; the fast variants measured the other way round (4.5 against 3.8).
 template <typename T, int LOG2N, int VAR> constexpr int points_per_thread()
 {
-    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeFor<T, LOG2N>::P;
+    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeFor<T, LOG2N>::P;   // (any MFFT_P16384)
 }
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> struct BlockCfg {

@@ -64,11 +64,10 @@ void build_lds_twiddles(const LdsGeometry& g, std::vector<long double>* re, std:
     for (int s = 0; s < g.npass; ++s) {
         const int r = g.radix[s];
         if (s > 0) {
-            // powers stored per pass: all of 1..r-1, or the six generators of a radix-16 pass
-            static const int split16[6] = {1, 2, 3, 4, 8, 12};
+            // powers stored per pass: all of 1..r-1, or the generators of a radix-16 / radix-32 pass
             const int rows = tw_rows(r, g.split16 != 0);
             for (int row = 0; row < rows; ++row) {
-                const int i = (rows == r - 1) ? row + 1 : split16[row];
+                const int i = (rows == r - 1) ? row + 1 : tw_split_power(row);
                 for (int m = 0; m < ns; ++m) {
                     long double c, d;
                     unit_root((int64_t)m * i, (int64_t)ns * r, &c, &d);
