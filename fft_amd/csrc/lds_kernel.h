@@ -35,6 +35,9 @@
 #ifndef MFFT_BLOCK_MIN
 #define MFFT_BLOCK_MIN 256   // workgroup size when a signal needs fewer threads than this
 #endif
+#ifndef MFFT_BLOCK_2048
+#define MFFT_BLOCK_2048 1    // 1 = 2048-point signals (two waves) run in 128-thread workgroups
+#endif
 #ifndef MFFT_NT
 #define MFFT_NT 1            // 1 = non-temporal global loads/stores in the fast variants (+10 % on the 1024-point batch)
 #endif
@@ -681,7 +684,8 @@ template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices
 // points: 4.2 against 5.5 TB/s), the price of barriers over eight waves.  32 points per thread is a
 // 256-thread workgroup, two exchanges (32*16*16) and 234-252 VGPRs, two workgroups per CU:
 // plain 4.25 -> 4.6 TB/s, windowed 3.7 -> 4.6, Hann + power 3.55 -> 4.25.  complex128 (128 KiB of
-// LDS per signal: one workgroup per CU either way) measured the same or slower and keeps 16.
+// LDS per signal: one workgroup per CU either way) measured the same or slower and keeps 16, and
+// so does 4096 complex64 (32 per thread: 5.26 against 5.49 TB/s plain, 3.5 against 5.0 windowed).
 template <typename T, int LOG2N> struct SizeFor : SizeCfg<LOG2N> {};
 #if MFFT_P8192 == 32
 template <> struct SizeFor<float, 13> { static constexpr int P = 32; using RD = Radices<32, 16, 16, 1>; };
@@ -699,7 +703,9 @@ template <typename T, int LOG2N, int VAR> constexpr int points_per_thread()
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> struct BlockCfg {
     static constexpr int TX = (1 << LOG2N) / points_per_thread<T, LOG2N, VAR>();
-    static constexpr int BLOCK = TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN;
+    // a two-wave signal (2048 points) gets a workgroup of its own: its barriers then span two
+    // waves instead of four (+4 % plain complex64); one-wave signals need no barrier and share
+    static constexpr int BLOCK = (TX == 128 && MFFT_BLOCK_2048 != 0) ? 128 : (TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN);
 };
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_for()
