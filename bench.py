@@ -122,7 +122,7 @@ def secondary_configs(with_cpu):
     """Short single-GPU timings of the other BASELINE configurations (parity-test cases, not the
     headline): config 3 (2^24 complex64), config 4 (16384^2 complex64 through the slab
     decomposition, one rank) and config 5 (2^31 complex128 through the four-step decomposition,
-    one rank).  Each entry: ms per transform, GFLOP/s (5 N log2 N) and algorithmic GB/s (one read +
+    one rank, and as one plan).  Each entry: ms per transform, GFLOP/s (5 N log2 N) and algorithmic GB/s (one read +
     one write of the data); failures are recorded, never raised."""
     import numpy as np
     import torch
@@ -188,8 +188,18 @@ def secondary_configs(with_cpu):
         for lo in range(0, n1 * n2, 1 << 27):
             xr[lo:lo + (1 << 27)].normal_()
         t = timed(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True), 1)
-        out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5)
-        del x, xr
+        out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5,
+                                                          route="four-step decomposition, one rank")
+        ops.close()
+        torch.cuda.empty_cache()
+        # the same transform as ONE plan (four global passes, natural order, no re-layout pass): what a
+        # single GPU should run; the four-step route above is the one-rank case of the multi-GPU path
+        y = torch.empty_like(x)
+        plan = fft_amd.Plan(n1 * n2, dtype=fft_amd.C128)
+        t = timed(lambda: plan.exec(x, y, stream=stream), 1)
+        out[f"config5_1d_2pow{lg}_c128_one_gpu_single_plan"] = entry(t, n1 * n2, lg, 16, launches=plan.launches)
+        plan.destroy()
+        del x, xr, y
     except Exception as exc:                                  # noqa: BLE001
         out["config5_1d_c128_one_gpu"] = {"error": repr(exc)[:200]}
     ops.close()

@@ -137,3 +137,33 @@ def test_largest_app_length():
         ph = ((j * int(k)) % n).astype(np.float64) / n                 # exact: j*k < 2^63
         want = np.abs(dt * np.sum(xw * np.exp(-2j * np.pi * ph))) ** 2
         assert abs(S[k] - want) <= 1e-11 * S[k_peak] + 1e-9 * want, (k, S[k], want)
+
+
+def test_cfg5_2pow31_c128_single_plan():
+    """The same 2^31-point complex128 transform as ONE plan on one GPU: four global passes,
+    natural-order output, 64 GiB of workspace."""
+    import torch
+    import fft_amd as fa
+    torch.cuda.set_device(0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs about 130 GiB of free device memory")
+    n = 1 << 31
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.empty(n, dtype=torch.complex128, device="cuda")
+    xr = torch.view_as_real(x)
+    for lo in range(0, n, 1 << 27):
+        xr[lo:lo + (1 << 27)].normal_(generator=g)
+    y = torch.empty_like(x)
+    with fa.Plan(n, dtype=fa.C128) as p:
+        assert p.launches == 4
+        p.exec(x, y, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    e_in, e_out = _energy(x), _energy(y)
+    assert abs(e_out / (n * e_in) - 1.0) < 1e-12
+    ks = [0, 1, 255, 256, 65535, 65536, n // 2 - 1, n // 2, n - 256, n - 1, 1234567891, 987654321]
+    got = y[torch.tensor(ks, device="cuda")].cpu().numpy()
+    del y
+    torch.cuda.empty_cache()
+    want = _direct_bins_1d(x, ks)
+    assert np.max(np.abs(got - want)) / math.sqrt(e_in) < 1e-12
