@@ -243,11 +243,22 @@ def main():
         torch.cuda.synchronize()
 
     sync_all()      # the first barrier sets up the communicator: keep that out of the settled phase
+    # untimed: sustained load until the clocks have settled -- at least `settle` seconds, then on
+    # until a 100-launch batch is within 1 % of the fastest batch seen (at most 4 x `settle`)
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle:
+    fastest = float("inf")
+    while True:
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
         for _ in range(100):
             step()
+        b1.record()
         torch.cuda.synchronize()
+        took = b0.elapsed_time(b1)
+        fastest = min(fastest, took)
+        waited = time.perf_counter() - t_settle
+        if waited >= args.settle and (took <= 1.01 * fastest or waited >= 4 * args.settle):
+            break
     for _ in range(args.warmup):
         step()
     # Average launch duration of the (single) kernel of a step: two events on the
