@@ -304,17 +304,26 @@ template <class RD> constexpr int tw_total_elems()
 
 // Which source the fast variants take their twiddles / window from, and the LDS
 // bytes the shared tables need behind the data slots.
-template <class RD, int TX, int P, int VAR> constexpr int tw_source()
+template <typename T, class RD, int TX, int P, int VAR> constexpr int tw_source()
 {
     if (RD::npass < 2) return TW_GLOBAL;
-    if (MFFT_TW_SRC == TW_REG) return twreg_count<RD, TX, P>() <= (RD::split16 ? 12 : 18) ? TW_REG : TW_GLOBAL;
+    if (MFFT_TW_SRC == TW_REG) {
+        // measured exceptions to "registers where the set is small enough":
+        // complex128 from 1024 points reads the (L1/L2-resident) table per signal: a register copy
+        // is 4 VGPRs per twiddle there (plain +2..6 %, Hann + power at 2048 points +13 %);
+        // the 4096-point complex64 Hann + power kernel, which also keeps 16 window samples per
+        // lane, takes the table from LDS (4.7 -> 5.3 TB/s)
+        if (sizeof(T) == 8 && RD::n >= 1024) return TW_GLOBAL;
+        if (sizeof(T) == 4 && RD::n == 4096 && VAR == V_HANN_POWER && tw_total_elems<RD>() <= 2048) return TW_LDS;
+        return twreg_count<RD, TX, P>() <= (RD::split16 ? 12 : 18) ? TW_REG : TW_GLOBAL;
+    }
     if (MFFT_TW_SRC == TW_LDS) return tw_total_elems<RD>() <= 2048 ? TW_LDS : TW_GLOBAL;
     return TW_GLOBAL;
 }
 template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_lds_bytes()
 {
     size_t b = 0;
-    if (tw_source<RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
+    if (tw_source<T, RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
     if (VAR == V_HANN_POWER && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
     return b;
 }
@@ -332,7 +341,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER);
     constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
     constexpr int TWN = twreg_count<RD, TX, P>();
-    constexpr int TWSRC = tw_source<RD, TX, P, VAR>();
+    constexpr int TWSRC = tw_source<T, RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
     // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
