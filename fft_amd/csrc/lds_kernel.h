@@ -485,6 +485,14 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             int jj[P];
 #pragma unroll
             for (int e = 0; e < P; ++e) { const int j = t + TX * e; jj[e] = j < last ? j : last; }
+            // the indices do not depend on the signal; computed outside the batch loop, the element
+            // addresses of x, window and premultiplier stay live in ~100 registers, which at 512
+            // points leaves one resident workgroup per CU: keep them per-signal work there
+            // (+12..33 %; the shorter lengths measured 2-5 % slower with it)
+            if constexpr (N == 512) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) asm volatile("" : "+v"(jj[e]));
+            }
             if (a.real_in) {
                 const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + bl * a.in_stride;
 #pragma unroll
