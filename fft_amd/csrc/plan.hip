@@ -397,7 +397,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.out_lseg = io.out_seg ? ilog2(io.out_seg) : 30;
         }
         else variant = io.power ? V_GEN_POWER : V_GEN_CPLX;
-        if ((variant == V_PLAIN || variant == V_HANN_POWER) && d_wave_tw) {
+        if (bare && d_wave_tw) {
             // shortest lengths: the signal lives across lanes (DPP / swizzle exchanges, 16 B per lane)
             WaveArgs<T> w{};
             w.in = static_cast<const cx<T>*>(io.in);
@@ -406,8 +406,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             w.win = io.win;
             w.units = nb * n * (int64_t)sizeof(cx<T>) / 16;
             w.scale = io.scale;
-            if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, variant == V_HANN_POWER, w, s);
-            else return launch_wave_c128(log2n, variant == V_HANN_POWER, w, s);
+            if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, io.win != nullptr, io.power, w, s);
+            else return launch_wave_c128(log2n, io.win != nullptr, io.power, w, s);
         }
         const bool general = variant == V_GEN_POWER || variant == V_GEN_CPLX;
         const bool stage_i = general && io.in_seg > 0, stage_o = general && io.out_seg > 0;

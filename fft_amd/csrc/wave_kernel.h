@@ -25,9 +25,9 @@ namespace mfft {
 
 template <typename T> struct WaveArgs {
     const cx<T>* in;
-    void* out;             // complex bins, or (HANNPOWER) the real power spectrum
+    void* out;             // complex bins, or (POWER) the real power spectrum
     const cx<T>* tw;       // W_N^j = exp(-2*pi*i*j/N), j < N/2
-    const T* win;          // HANNPOWER: window of N samples
+    const T* win;          // WIN: window of N samples
     int64_t units;         // 16-byte units in the whole batch = batch * N / K
     T scale;
 };
@@ -65,8 +65,8 @@ __device__ __forceinline__ void wave_stage(cx<T> (&x)[K], const cx<T> (&w)[K], b
     }
 }
 
-// HANNPOWER: x[j] *= win[j] on load, out = |scale * X|^2 (the fused epilogue of BASELINE config 2)
-template <typename T, int LOG2N, int UNROLL, bool HANNPOWER>
+// WIN: x[j] *= win[j] on load; POWER: out = |scale * X|^2 (both: the fused form of BASELINE config 2)
+template <typename T, int LOG2N, int UNROLL, bool WIN, bool POWER>
 __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 {
     constexpr int N = 1 << LOG2N;
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
     }
     T win[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) win[r] = HANNPOWER ? a.win[li * K + r] : (T)1;
+    for (int r = 0; r < K; ++r) win[r] = WIN ? a.win[li * K + r] : (T)1;
     // bit-reversed position of each element, relative to the wave's block
     int pos[K];
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
                 x[u][0] = C{(T)__longlong_as_double(((long long)v.y << 32) | v.x),
                             (T)__longlong_as_double(((long long)v.w << 32) | v.z)};
             }
-            if constexpr (HANNPOWER) {
+            if constexpr (WIN) {
 #pragma unroll
                 for (int r = 0; r < K; ++r) { x[u][r].x *= win[r]; x[u][r].y *= win[r]; }
             }
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 #pragma unroll
                 for (int r = 0; r < K; ++r) {
                     const T re = x[u][r].x * a.scale, im = x[u][r].y * a.scale;
-                    if constexpr (HANNPOWER) st_stream(static_cast<T*>(a.out) + base * K + pos[r], re * re + im * im);
+                    if constexpr (POWER) st_stream(static_cast<T*>(a.out) + base * K + pos[r], re * re + im * im);
                     else st_stream(static_cast<C*>(a.out) + base * K + pos[r], C{re, im});
                 }
             }
@@ -152,11 +152,11 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
     }
 }
 
-template <typename T, int LOG2N, bool HANNPOWER>
+template <typename T, int LOG2N, bool WIN, bool POWER>
 int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int UNROLL = 4;
-    auto kern = fft_wave_kernel<T, LOG2N, UNROLL, HANNPOWER>;
+    auto kern = fft_wave_kernel<T, LOG2N, UNROLL, WIN, POWER>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
@@ -174,13 +174,14 @@ int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 
 // complex64: 4..128 points, complex128: 2..64 points
 template <typename T>
-int launch_wave_any(int log2n, bool hann_power, const WaveArgs<T>& a, hipStream_t s)
+int launch_wave_any(int log2n, bool win, bool power, const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int MAXLOG = sizeof(T) == 4 ? 7 : 6;
     constexpr int MINLOG = sizeof(T) == 4 ? 2 : 1;
     switch (log2n) {
 #define MFFT_W(L) case L: if constexpr (L >= MINLOG && L <= MAXLOG) \
-        return hann_power ? launch_wave_one<T, L, true>(a, s) : launch_wave_one<T, L, false>(a, s); else break;
+        return win ? (power ? launch_wave_one<T, L, true, true>(a, s) : launch_wave_one<T, L, true, false>(a, s)) \
+                   : (power ? launch_wave_one<T, L, false, true>(a, s) : launch_wave_one<T, L, false, false>(a, s)); else break;
         MFFT_W(1) MFFT_W(2) MFFT_W(3) MFFT_W(4) MFFT_W(5) MFFT_W(6) MFFT_W(7)
 #undef MFFT_W
     }

@@ -170,7 +170,7 @@ def test_layouts_through_every_route(fa, dtype):
 def test_short_lengths_both_kernel_families(fa, dtype, monkeypatch):
     """Lengths up to 128 / 64 points run lane-distributed by default; MFFT_NO_WAVE=1 (read when the
     plan is built) selects the LDS-resident kernel for the same lengths.  Both must meet the bar,
-    for the plain and the fused Hann + power variants, on ragged batches."""
+    for the plain, window-only, power-only and fused Hann + power variants, on ragged batches."""
     cdt = np.complex64 if dtype == 0 else np.complex128
     for n in (2, 4, 8, 16, 32, 64, 128):
         for batch in (1, 5, 63, 1000):
@@ -183,9 +183,15 @@ def test_short_lengths_both_kernel_families(fa, dtype, monkeypatch):
                     monkeypatch.delenv("MFFT_NO_WAVE", raising=False)
                 with fa.Plan(n, batch=batch, dtype=dtype) as p:
                     assert rel_l2(p.exec_host(x, scale=2.0), 2.0 * ref) < TOL[dtype], (n, batch, no_wave)
+                with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.POWER) as p:         # power only
+                    S = p.exec_host(x, scale=0.5)
+                assert rel_l2(S, np.abs(0.5 * ref) ** 2) < TOL[dtype], (n, batch, no_wave)
                 if n >= 4:
+                    xw = x.astype(np.complex128) * np.hanning(n)
                     with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.HANN | fa.POWER) as p:
                         S = p.exec_host(x, scale=0.5)
-                    want = np.abs(0.5 * np.fft.fft(x.astype(np.complex128) * np.hanning(n))) ** 2
-                    assert rel_l2(S, want) < TOL[dtype], (n, batch, no_wave)
+                    assert rel_l2(S, np.abs(0.5 * np.fft.fft(xw)) ** 2) < TOL[dtype], (n, batch, no_wave)
+                    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.HANN) as p:      # window only
+                        F = p.exec_host(x, scale=0.5)
+                    assert rel_l2(F, 0.5 * np.fft.fft(xw)) < TOL[dtype], (n, batch, no_wave)
     monkeypatch.delenv("MFFT_NO_WAVE", raising=False)
