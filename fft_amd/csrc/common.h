@@ -74,6 +74,8 @@ enum Variant {
     V_GEN_CPLX = 2,    // general prologue (pad / window / premultiplier / real / conj) -> complex out
     V_GEN_POWER = 3,   // general prologue -> power out (+ optional per-signal stats)
     V_SEG = 4,         // V_PLAIN over power-of-two segmented layouts (exchange packing of the multi-GPU paths)
+    V_WIN = 5,         // complex in * register-resident window -> scaled complex out
+    V_POW = 6,         // complex in -> power out
     V_COUNT = 5
 };
 

@@ -324,7 +324,7 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 {
     size_t b = 0;
     if (tw_source<T, RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
-    if (VAR == V_HANN_POWER && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
+    if ((VAR == V_HANN_POWER || VAR == V_WIN) && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
     return b;
 }
 
@@ -338,7 +338,8 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int SLOTS = BLOCK / TX;
     constexpr int NPASS = RD::npass;
     constexpr int LDS_ELEMS = ((lds_pad<PADSHIFT>(N - 1) + 1 + 1) / 2) * 2;   // keep slots 16-byte aligned
-    constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER);
+    constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER || VAR == V_POW);
+    constexpr bool FASTWIN = (VAR == V_HANN_POWER || VAR == V_WIN);   // window samples held per lane
     constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
     constexpr int TWN = twreg_count<RD, TX, P>();
     constexpr int TWSRC = tw_source<T, RD, TX, P, VAR>();
@@ -362,14 +363,14 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     if constexpr (TWSRC == TW_LDS) {
         for (int i = threadIdx.x; i < tw_total_elems<RD>(); i += BLOCK) twl[i] = a.tw[i];
     }
-    if constexpr (VAR == V_HANN_POWER && WINSRC == WIN_LDS) {
+    if constexpr (FASTWIN && WINSRC == WIN_LDS) {
         for (int i = threadIdx.x; i < N; i += BLOCK) winl[i] = a.win[i];
     }
-    if constexpr (TWSRC == TW_LDS || (VAR == V_HANN_POWER && WINSRC == WIN_LDS)) __syncthreads();
+    if constexpr (TWSRC == TW_LDS || (FASTWIN && WINSRC == WIN_LDS)) __syncthreads();
 
     // ---- per-lane constants, fetched once ---------------------------------
-    T wreg[(VAR == V_HANN_POWER && WINSRC == WIN_REG) ? P : 1];
-    if constexpr (VAR == V_HANN_POWER && WINSRC == WIN_REG) {
+    T wreg[(FASTWIN && WINSRC == WIN_REG) ? P : 1];
+    if constexpr (FASTWIN && WINSRC == WIN_REG) {
 #pragma unroll
         for (int e = 0; e < P; ++e) wreg[e] = a.win[t + TX * e];
     }
@@ -432,7 +433,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
             }
-            if constexpr (VAR == V_HANN_POWER) {
+            if constexpr (FASTWIN) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
                     T w;
@@ -771,6 +772,8 @@ int launch_variant(int variant, const KArgs<T>& a, int grid, hipStream_t s)
     switch (variant) {
     case V_PLAIN: return launch_one<T, LOG2N, V_PLAIN>(a, grid, s);
     case V_HANN_POWER: return launch_one<T, LOG2N, V_HANN_POWER>(a, grid, s);
+    case V_WIN: return launch_one<T, LOG2N, V_WIN>(a, grid, s);
+    case V_POW: return launch_one<T, LOG2N, V_POW>(a, grid, s);
     case V_GEN_CPLX: return launch_one<T, LOG2N, V_GEN_CPLX>(a, grid, s);
     case V_GEN_POWER: return launch_one<T, LOG2N, V_GEN_POWER>(a, grid, s);
     case V_SEG: return launch_one<T, LOG2N, V_SEG>(a, grid, s);

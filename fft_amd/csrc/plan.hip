@@ -388,6 +388,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
                               !io.win && !io.power && io.n_in == n && io.n_out == n && seg_ok;
         int variant;
         if (io.power && io.win && bare) variant = V_HANN_POWER;
+        else if (io.win && bare) variant = V_WIN;
+        else if (io.power && bare) variant = V_POW;
         // the largest lengths run faster through V_SEG's scalar-offset addressing even when dense
         // (16384 complex64: 260 -> 237 us per 2^26 points)
         else if (!io.power && !io.win && bare && log2n < 13) variant = V_PLAIN;

@@ -195,3 +195,21 @@ def test_short_lengths_both_kernel_families(fa, dtype, monkeypatch):
                         F = p.exec_host(x, scale=0.5)
                     assert rel_l2(F, 0.5 * np.fft.fft(xw)) < TOL[dtype], (n, batch, no_wave)
     monkeypatch.delenv("MFFT_NO_WAVE", raising=False)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("log2n", list(range(8, 15)))
+def test_window_only_and_power_only(fa, dtype, log2n):
+    """Full-length dense transforms with only a window (complex out) or only the power epilogue:
+    their own fast variants of the LDS-resident kernel (tile passes beyond its range)."""
+    n = 1 << log2n
+    batch = 9 if n >= 2048 else 41
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), 7 * n + dtype, cdt)
+    xw = x.astype(np.complex128) * np.hanning(n)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.HANN) as p:
+        F = p.exec_host(x, scale=0.25)
+    assert F.dtype == cdt and rel_l2(F, 0.25 * np.fft.fft(xw)) < TOL[dtype]
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.POWER) as p:
+        S = p.exec_host(x, scale=0.25)
+    assert rel_l2(S, np.abs(0.25 * np.fft.fft(x.astype(np.complex128))) ** 2) < TOL[dtype]
