@@ -76,6 +76,7 @@ enum Variant {
     V_SEG = 4,         // V_PLAIN over power-of-two segmented layouts (exchange packing of the multi-GPU paths)
     V_WIN = 5,         // complex in * register-resident window -> scaled complex out
     V_POW = 6,         // complex in -> power out
+    V_REAL = 7,        // real in (full length, contiguous) -> scaled complex out
     V_COUNT = 5
 };
 

@@ -104,6 +104,14 @@ template <typename T> __device__ __forceinline__ void st_stream(cx<T>* p, cx<T> 
     *p = v;
 #endif
 }
+template <typename T> __device__ __forceinline__ T ld_stream_real(const T* p)
+{
+#if MFFT_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 template <typename T> __device__ __forceinline__ void st_stream(T* p, T v)
 {
 #if MFFT_NT
@@ -412,6 +420,11 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 const int64_t off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
                 v[e] = ld_stream(src + off + t);
             }
+        } else if constexpr (VAR == V_REAL) {
+            const int64_t bl = active ? b : a.batch - 1;
+            const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + bl * a.in_stride;
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = C{ld_stream_real(src + t + TX * e), (T)0};
         } else if constexpr (!GENERAL) {
             // a slot beyond the batch re-reads the last signal and skips its stores: no branch here
             const int64_t bl = active ? b : a.batch - 1;
@@ -774,6 +787,7 @@ int launch_variant(int variant, const KArgs<T>& a, int grid, hipStream_t s)
     case V_HANN_POWER: return launch_one<T, LOG2N, V_HANN_POWER>(a, grid, s);
     case V_WIN: return launch_one<T, LOG2N, V_WIN>(a, grid, s);
     case V_POW: return launch_one<T, LOG2N, V_POW>(a, grid, s);
+    case V_REAL: return launch_one<T, LOG2N, V_REAL>(a, grid, s);
     case V_GEN_CPLX: return launch_one<T, LOG2N, V_GEN_CPLX>(a, grid, s);
     case V_GEN_POWER: return launch_one<T, LOG2N, V_GEN_POWER>(a, grid, s);
     case V_SEG: return launch_one<T, LOG2N, V_SEG>(a, grid, s);

@@ -213,3 +213,18 @@ def test_window_only_and_power_only(fa, dtype, log2n):
     with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.POWER) as p:
         S = p.exec_host(x, scale=0.25)
     assert rel_l2(S, np.abs(0.25 * np.fft.fft(x.astype(np.complex128))) ** 2) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n", [2, 16, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_real_input_full_length(fa, dtype, n):
+    """np.fft.fft on real arrays (numpy promotes them to complex): real samples are read as they
+    are, 4 / 8 bytes per point."""
+    if dtype == 1 and n > 8192:
+        pytest.skip("complex128 single-kernel range ends at 8192")
+    rdt = np.float32 if dtype == 0 else np.float64
+    batch = 6 if n >= 2048 else 35
+    xr = np.random.default_rng(n + dtype).standard_normal((batch, n)).astype(rdt)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
+        y = p.exec_host(xr, scale=3.0)
+    assert rel_l2(y, 3.0 * np.fft.fft(xr.astype(np.float64))) < TOL[dtype]
