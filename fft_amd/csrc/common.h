@@ -110,8 +110,8 @@ int device_cu_count();
 template <typename T> struct WaveArgs;
 constexpr int kWaveMinLog2C64 = 2, kWaveMaxLog2C64 = 7;     // 4..128 points
 constexpr int kWaveMinLog2C128 = 1, kWaveMaxLog2C128 = 6;   // 2..64 points
-int launch_wave_c64(int log2n, bool win, bool power, const WaveArgs<float>& a, hipStream_t s);
-int launch_wave_c128(int log2n, bool win, bool power, const WaveArgs<double>& a, hipStream_t s);
+int launch_wave_c64(int log2n, bool win, bool power, bool real_in, const WaveArgs<float>& a, hipStream_t s);
+int launch_wave_c128(int log2n, bool win, bool power, bool real_in, const WaveArgs<double>& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Arguments of the global-pass (tile) kernels, see tile_kernel.h

@@ -404,17 +404,19 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.out_lseg = io.out_seg ? ilog2(io.out_seg) : 30;
         }
         else variant = io.power ? V_GEN_POWER : V_GEN_CPLX;
-        if (bare && d_wave_tw) {
+        const bool bare_real = io.real_in && !io.power && !io.win && !io.pre && !io.post && !io.conj_in && !io.conj_out &&
+                               !io.stats && full;
+        if ((bare || bare_real) && d_wave_tw) {
             // shortest lengths: the signal lives across lanes (DPP / swizzle exchanges, 16 B per lane)
             WaveArgs<T> w{};
-            w.in = static_cast<const cx<T>*>(io.in);
+            w.in = io.in;
             w.out = io.out;
             w.tw = static_cast<const cx<T>*>(d_wave_tw);
             w.win = io.win;
             w.units = nb * n * (int64_t)sizeof(cx<T>) / 16;
             w.scale = io.scale;
-            if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, io.win != nullptr, io.power, w, s);
-            else return launch_wave_c128(log2n, io.win != nullptr, io.power, w, s);
+            if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, io.win != nullptr, io.power, io.real_in != 0, w, s);
+            else return launch_wave_c128(log2n, io.win != nullptr, io.power, io.real_in != 0, w, s);
         }
         const bool general = variant == V_GEN_POWER || variant == V_GEN_CPLX;
         const bool stage_i = general && io.in_seg > 0, stage_o = general && io.out_seg > 0;

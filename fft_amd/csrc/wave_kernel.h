@@ -24,7 +24,7 @@
 namespace mfft {
 
 template <typename T> struct WaveArgs {
-    const cx<T>* in;
+    const void* in;        // complex samples, or (REAL) real samples
     void* out;             // complex bins, or (POWER) the real power spectrum
     const cx<T>* tw;       // W_N^j = exp(-2*pi*i*j/N), j < N/2
     const T* win;          // WIN: window of N samples
@@ -66,7 +66,8 @@ __device__ __forceinline__ void wave_stage(cx<T> (&x)[K], const cx<T> (&w)[K], b
 }
 
 // WIN: x[j] *= win[j] on load; POWER: out = |scale * X|^2 (both: the fused form of BASELINE config 2)
-template <typename T, int LOG2N, int UNROLL, bool WIN, bool POWER>
+// REAL: the input holds real samples (K per lane, 8 bytes)
+template <typename T, int LOG2N, int UNROLL, bool WIN, bool POWER, bool REAL = false>
 __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 {
     constexpr int N = 1 << LOG2N;
@@ -111,7 +112,15 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t unit = ((b0 + u) << 6) + lane;
             V4 v = {0u, 0u, 0u, 0u};
-            if (unit < a.units) v = __builtin_nontemporal_load(reinterpret_cast<const V4*>(a.in) + unit);
+            if constexpr (REAL) {
+                using V2 = unsigned int __attribute__((ext_vector_type(2)));
+                V2 r = {0u, 0u};
+                if (unit < a.units) r = __builtin_nontemporal_load(reinterpret_cast<const V2*>(a.in) + unit);
+                if constexpr (K == 2) v = V4{r.x, 0u, r.y, 0u};      // two floats -> (re, 0), (re, 0)
+                else v = V4{r.x, r.y, 0u, 0u};                       // one double -> (re, 0)
+            } else {
+                if (unit < a.units) v = __builtin_nontemporal_load(reinterpret_cast<const V4*>(a.in) + unit);
+            }
             if constexpr (K == 2) {
                 x[u][0] = C{__uint_as_float(v.x), __uint_as_float(v.y)};
                 x[u][1] = C{__uint_as_float(v.z), __uint_as_float(v.w)};
@@ -152,11 +161,11 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
     }
 }
 
-template <typename T, int LOG2N, bool WIN, bool POWER>
+template <typename T, int LOG2N, bool WIN, bool POWER, bool REAL = false>
 int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int UNROLL = 4;
-    auto kern = fft_wave_kernel<T, LOG2N, UNROLL, WIN, POWER>;
+    auto kern = fft_wave_kernel<T, LOG2N, UNROLL, WIN, POWER, REAL>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));
@@ -174,13 +183,13 @@ int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 
 // complex64: 4..128 points, complex128: 2..64 points
 template <typename T>
-int launch_wave_any(int log2n, bool win, bool power, const WaveArgs<T>& a, hipStream_t s)
+int launch_wave_any(int log2n, bool win, bool power, bool real_in, const WaveArgs<T>& a, hipStream_t s)
 {
     constexpr int MAXLOG = sizeof(T) == 4 ? 7 : 6;
     constexpr int MINLOG = sizeof(T) == 4 ? 2 : 1;
     switch (log2n) {
 #define MFFT_W(L) case L: if constexpr (L >= MINLOG && L <= MAXLOG) \
-        return win ? (power ? launch_wave_one<T, L, true, true>(a, s) : launch_wave_one<T, L, true, false>(a, s)) \
+        return real_in ? launch_wave_one<T, L, false, false, true>(a, s) : win ? (power ? launch_wave_one<T, L, true, true>(a, s) : launch_wave_one<T, L, true, false>(a, s)) \
                    : (power ? launch_wave_one<T, L, false, true>(a, s) : launch_wave_one<T, L, false, false>(a, s)); else break;
         MFFT_W(1) MFFT_W(2) MFFT_W(3) MFFT_W(4) MFFT_W(5) MFFT_W(6) MFFT_W(7)
 #undef MFFT_W

@@ -216,7 +216,7 @@ def test_window_only_and_power_only(fa, dtype, log2n):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("n", [2, 16, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_real_input_full_length(fa, dtype, n):
     """np.fft.fft on real arrays (numpy promotes them to complex): real samples are read as they
     are, 4 / 8 bytes per point."""
