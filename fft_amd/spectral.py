@@ -22,7 +22,6 @@ these functions raise.
 from __future__ import annotations
 
 import ctypes
-import itertools
 import threading
 from collections import OrderedDict
 
@@ -179,6 +178,35 @@ def _solve_normal(G, r, yy, cols):
         p = p / total
     res2 = yy - 2.0 * np.real(np.vdot(coef, rs)) + np.real(np.vdot(coef, Gs @ coef))
     return coef, p, float(np.sqrt(max(res2, 0.0)))
+
+
+def _sign_search(G, r, yy, k, chunk=4096):
+    """The 2^k sign search of streamlit_app_combined.py:239-246 on the normal equations of the 2k
+    columns exp(-i(+|w_i|)t) (first k) and exp(-i(-|w_i|)t) (last k): for every sign pattern, in the
+    order itertools.product((-1, +1), repeat=k) visits them, the minimum-norm fit on its k columns;
+    returns (signs, weights) of the first pattern with the smallest residual.  All patterns of a
+    chunk are solved in one stacked pseudo-inverse (Hermitian k x k blocks) instead of one lstsq
+    call each."""
+    best = (np.inf, None, None)
+    total = 1 << k
+    shifts = np.arange(k - 1, -1, -1)
+    base = np.arange(k)
+    for lo in range(0, total, chunk):
+        idx = np.arange(lo, min(total, lo + chunk))
+        plus = ((idx[:, None] >> shifts) & 1).astype(bool)            # bit i set: sign +1 at position i
+        cols = np.where(plus, base, k + base)                         # (m, k)
+        Gs = G[cols[:, :, None], cols[:, None, :]]                    # (m, k, k)
+        rs = r[cols]                                                  # (m, k)
+        coef = np.einsum("mij,mj->mi", np.linalg.pinv(Gs, rcond=1e-12, hermitian=True), rs)
+        res2 = yy - 2.0 * np.real(np.einsum("mi,mi->m", coef.conj(), rs)) \
+            + np.real(np.einsum("mi,mij,mj->m", coef.conj(), Gs, coef))
+        res2 = np.maximum(res2, 0.0)                                  # the reference compares sqrt(max(., 0))
+        j = int(np.argmin(res2))
+        if res2[j] < best[0]:
+            p = np.clip(coef[j].real, 0.0, None)
+            tot = p.sum()
+            best = (float(res2[j]), np.where(plus[j], 1.0, -1.0), p / tot if tot > 0 else p)
+    return best[1], best[2]
 
 
 # --------------------------------------------------------------------------- estimator A
@@ -354,13 +382,8 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
     demod_mu = mu if (demod and mu != 0.0) else 0.0
     G, r, yy = _normal_equations(f_t, win if use_hann else None, times, np.concatenate((mags, -mags)),
                                  mu=demod_mu)
-    best_res, best_E, best_p = np.inf, None, None
-    for signs in itertools.product((-1.0, +1.0), repeat=k):
-        E_try = np.array([s * m for s, m in zip(signs, mags)])
-        cols = np.array([i if sg > 0 else k + i for i, sg in enumerate(signs)])
-        _, p_try, res = _solve_normal(G, r, yy, cols)
-        if res < best_res:
-            best_res, best_E, best_p = res, E_try, p_try
+    signs, best_p = _sign_search(G, r, yy, k)
+    best_E = signs * mags
     E_phys = best_E - mu
     order = np.argsort(E_phys)
     return E_phys[order], best_p[order], omega, S, mu

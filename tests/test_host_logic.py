@@ -140,3 +140,34 @@ def test_by_height_matches_full_sort():
     cand = np.arange(1000)
     got = list(_by_height(cand, h))
     assert sorted(got) == list(range(1000)) and np.all(np.diff(h[got]) <= 0)
+
+
+def test_sign_search_matches_one_fit_per_pattern():
+    """The stacked pseudo-inverse form of the 2^k sign search picks the pattern, and returns the
+    weights, of the pattern-by-pattern loop (first smallest residual), also with a zero-frequency
+    column pair (identical columns) and with coincident magnitudes."""
+    import itertools
+    from fft_amd import spectral as sp
+    rng = np.random.default_rng(3)
+    n0 = 400
+    t = np.arange(n0) * 0.05
+    win = np.hanning(n0)
+    for mags, truth in (([0.7, 2.1, 3.3], [-0.7, 2.1, -3.3]), ([0.0, 1.3], [0.0, 1.3]),
+                        ([0.5, 0.5000000001, 2.0], [0.5, -0.5, 2.0]), ([1.1], [-1.1]),
+                        ([0.3, 0.9, 1.7, 2.2, 3.1], [0.3, -0.9, 1.7, 2.2, -3.1])):
+        mags = np.array(mags)
+        k = len(mags)
+        y = sum((0.2 + 0.1 * i) * np.exp(-1j * e * t) for i, e in enumerate(truth)) * win
+        y = y + 1e-3 * (rng.standard_normal(n0) + 1j * rng.standard_normal(n0))
+        B = np.exp(-1j * np.outer(t, np.concatenate((mags, -mags)))) * win[:, None]
+        G, r, yy = B.conj().T @ B, B.conj().T @ y, float(np.vdot(y, y).real)
+        best = (np.inf, None, None)
+        for signs in itertools.product((-1.0, +1.0), repeat=k):
+            cols = np.array([i if sg > 0 else k + i for i, sg in enumerate(signs)])
+            _, p, res = sp._solve_normal(G, r, yy, cols)
+            if res < best[0]:
+                best = (res, np.array(signs), p)
+        signs, p = sp._sign_search(G, r, yy, k, chunk=5)              # several chunks
+        nz = mags > 1e-9                                              # the sign of a zero frequency is free
+        assert np.array_equal(signs[nz], best[1][nz]), (mags, signs, best[1])
+        assert np.allclose(p, best[2], atol=1e-9)
