@@ -77,6 +77,8 @@ enum Variant {
     V_WIN = 5,         // complex in * register-resident window -> scaled complex out
     V_POW = 6,         // complex in -> power out
     V_REAL = 7,        // real in (full length, contiguous) -> scaled complex out
+    V_HANN_POWER_STATS = 8,   // V_HANN_POWER + per-signal max / sum / centroid (the apps' own flag set)
+    V_POW_STATS = 9,   // V_POW + the same statistics
     V_COUNT = 5
 };
 

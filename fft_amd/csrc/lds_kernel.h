@@ -332,7 +332,7 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 {
     size_t b = 0;
     if (tw_source<T, RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
-    if ((VAR == V_HANN_POWER || VAR == V_WIN) && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
+    if ((VAR == V_HANN_POWER || VAR == V_WIN || VAR == V_HANN_POWER_STATS) && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
     return b;
 }
 
@@ -346,8 +346,9 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int SLOTS = BLOCK / TX;
     constexpr int NPASS = RD::npass;
     constexpr int LDS_ELEMS = ((lds_pad<PADSHIFT>(N - 1) + 1 + 1) / 2) * 2;   // keep slots 16-byte aligned
-    constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER || VAR == V_POW);
-    constexpr bool FASTWIN = (VAR == V_HANN_POWER || VAR == V_WIN);   // window samples held per lane
+    constexpr bool FASTSTATS = (VAR == V_HANN_POWER_STATS || VAR == V_POW_STATS);
+    constexpr bool POWER = (VAR == V_HANN_POWER || VAR == V_GEN_POWER || VAR == V_POW || FASTSTATS);
+    constexpr bool FASTWIN = (VAR == V_HANN_POWER || VAR == V_WIN || VAR == V_HANN_POWER_STATS);   // window samples held per lane
     constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
     constexpr int TWN = twreg_count<RD, TX, P>();
     constexpr int TWSRC = tw_source<T, RD, TX, P, VAR>();
@@ -598,7 +599,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, s[e]);
                 }
             }
-            if constexpr (VAR == V_GEN_POWER) {
+            if constexpr (VAR == V_GEN_POWER || FASTSTATS) {
                 if (a.stats != nullptr) {
                     double mx = 0.0, sm = 0.0, sk = 0.0;
 #pragma unroll
@@ -788,6 +789,8 @@ int launch_variant(int variant, const KArgs<T>& a, int grid, hipStream_t s)
     case V_WIN: return launch_one<T, LOG2N, V_WIN>(a, grid, s);
     case V_POW: return launch_one<T, LOG2N, V_POW>(a, grid, s);
     case V_REAL: return launch_one<T, LOG2N, V_REAL>(a, grid, s);
+    case V_HANN_POWER_STATS: return launch_one<T, LOG2N, V_HANN_POWER_STATS>(a, grid, s);
+    case V_POW_STATS: return launch_one<T, LOG2N, V_POW_STATS>(a, grid, s);
     case V_GEN_CPLX: return launch_one<T, LOG2N, V_GEN_CPLX>(a, grid, s);
     case V_GEN_POWER: return launch_one<T, LOG2N, V_GEN_POWER>(a, grid, s);
     case V_SEG: return launch_one<T, LOG2N, V_SEG>(a, grid, s);

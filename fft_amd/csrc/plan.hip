@@ -379,7 +379,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.scale = io.scale;
         const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n &&
                           io.in_seg == 0 && io.out_seg == 0;
-        const bool bare = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && !io.stats && full;
+        const bool bare_or_stats = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && full;
+        const bool bare = bare_or_stats && !io.stats;
         // V_SEG: power-of-two segments of at least n/P elements (P = points per thread), at most 2^30
         const int64_t seg_min = n / geo.p;
         const auto seg_fast = [&](int64_t sg) { return sg == 0 || (is_pow2(sg) && sg >= seg_min && sg <= (int64_t(1) << 30)); };
@@ -388,8 +389,10 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
                               !io.win && !io.power && io.n_in == n && io.n_out == n && seg_ok;
         int variant;
         if (io.power && io.win && bare) variant = V_HANN_POWER;
+        else if (io.power && io.win && bare_or_stats) variant = V_HANN_POWER_STATS;
         else if (io.win && bare) variant = V_WIN;
         else if (io.power && bare) variant = V_POW;
+        else if (io.power && bare_or_stats) variant = V_POW_STATS;
         // plain real -> complex: its own fast variant where that measured faster than the general one
         // (complex64, 256..4096 points: +4..25 %; shorter lengths and complex128 measured the same or slower)
         else if (io.real_in && !io.power && !io.win && !io.pre && !io.post && !io.conj_in && !io.conj_out && !io.stats && full &&

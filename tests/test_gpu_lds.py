@@ -228,3 +228,25 @@ def test_real_input_full_length(fa, dtype, n):
     with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
         y = p.exec_host(xr, scale=3.0)
     assert rel_l2(y, 3.0 * np.fft.fft(xr.astype(np.float64))) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("log2n", list(range(2, 15)))
+def test_power_with_statistics_full_length(fa, dtype, log2n):
+    """Dense full-length power spectra with per-signal statistics (the apps' own flag set,
+    final2.py:139-146, and the same without the window): max, sum and signed-bin centroid."""
+    n = 1 << log2n
+    batch = 7 if n >= 2048 else 45
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    x = _rand((batch, n), 11 * n + dtype, cdt)
+    f = np.fft.fftfreq(n) * n
+    tol = 1e-5 if dtype == 0 else 1e-11
+    for flags, xin in ((fa.HANN | fa.POWER | fa.STATS, x.astype(np.complex128) * np.hanning(n)),
+                       (fa.POWER | fa.STATS, x.astype(np.complex128))):
+        ref = np.abs(0.5 * np.fft.fft(xin)) ** 2
+        with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
+            S, st = p.exec_host(x, scale=0.5)
+        assert rel_l2(S, ref) < TOL[dtype], (n, flags)
+        np.testing.assert_allclose(st[:, 0], ref.max(axis=1), rtol=tol)
+        np.testing.assert_allclose(st[:, 1], ref.sum(axis=1), rtol=tol)
+        np.testing.assert_allclose(st[:, 2], (ref * f).sum(axis=1), rtol=0, atol=tol * np.abs(ref * f).sum(axis=1).max())

@@ -33,12 +33,14 @@ for k in range(a.lo, a.hi + 1):
     x = torch.view_as_complex(torch.randn((batch, n, 2), dtype=rdt, device="cuda"))
     y = torch.empty((batch, n), dtype=rdt if power else x.dtype, device="cuda")
     plans = {}
+    st = torch.zeros((batch, 3), dtype=torch.float64, device="cuda") if a.flags & 16 else None
+    stp = st.data_ptr() if st is not None else None
     for t, lib in libs.items():
         h = ctypes.c_void_p()
         assert lib.mfft_plan_1d(ctypes.byref(h), n, n, batch, a.dtype, a.flags) == 0, lib.mfft_last_error()
         plans[t] = h
         for _ in range(10):
-            lib.mfft_exec(h, x.data_ptr(), y.data_ptr(), 1.0, 0.0, 0.0, 1.0, None, stream)
+            lib.mfft_exec(h, x.data_ptr(), y.data_ptr(), 1.0, 0.0, 0.0, 1.0, stp, stream)
     torch.cuda.synchronize()
     res = {t: [] for t in a.tags}
     for _ in range(7):
@@ -46,7 +48,7 @@ for k in range(a.lo, a.hi + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                lib.mfft_exec(plans[t], x.data_ptr(), y.data_ptr(), 1.0, 0.0, 0.0, 1.0, None, stream)
+                lib.mfft_exec(plans[t], x.data_ptr(), y.data_ptr(), 1.0, 0.0, 0.0, 1.0, stp, stream)
             e1.record(); e1.synchronize()
             res[t].append(e0.elapsed_time(e1) / 10 * 1e-3)
     byts = n * batch * (esz + (esz // 2 if power else esz))
