@@ -621,10 +621,15 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     }
                     if (active && (t % W) == 0) {
                         double* st = a.stats + 3 * b;
-                        atomicMax(reinterpret_cast<unsigned long long*>(st),
-                                  (unsigned long long)__double_as_longlong(mx));
-                        atomicAdd(st + 1, sm);
-                        atomicAdd(st + 2, sk);
+                        if constexpr (TX <= 64) {
+                            // the whole signal was reduced inside one wave: plain stores
+                            st[0] = mx; st[1] = sm; st[2] = sk;
+                        } else {
+                            atomicMax(reinterpret_cast<unsigned long long*>(st),
+                                      (unsigned long long)__double_as_longlong(mx));
+                            atomicAdd(st + 1, sm);
+                            atomicAdd(st + 2, sk);
+                        }
                     }
                 }
             }
