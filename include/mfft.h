@@ -116,7 +116,9 @@ int mfft_plan_launches(mfft_plan plan, int* launches);
  * per signal {max_k S[k], sum_k S[k], sum_k f_k*S[k]} where S is the power
  * spectrum and f_k = k for k < ceil(n/2), k-n after (np.fft.fftfreq order, in
  * bins).  mu, t0, dt are read only with MFFT_DEMOD.  stream: a hipStream_t, or
- * NULL for the default stream.  The call is asynchronous. */
+ * NULL for the default stream.  The call is asynchronous.  d_out may be d_in for
+ * a dense complex -> complex transform of full-length input (n_in == n, no
+ * MFFT_REAL_IN, no MFFT_POWER); any other aliasing of the two is undefined. */
 int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
               double mu, double t0, double dt, double* d_stats, void* stream);
 

@@ -196,3 +196,29 @@ def test_pipelined_host_path_concurrent_callers(fa, monkeypatch):
     [t.join() for t in threads]
     [p.destroy() for p in plans]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_in_place_complex_transforms(fa, dtype):
+    """d_out == d_in is allowed for dense complex -> complex transforms of full-length input: every
+    route reads a signal (or writes its first pass to the workspace) before it stores."""
+    import torch
+    torch.cuda.set_device(0)
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    stream = torch.cuda.current_stream().cuda_stream
+    for n, batch in ((64, 300), (1024, 37), (8192, 5), (1 << 16, 3), (1 << 20, 1), (1000, 4), (24016, 1)):
+        x = _rand((batch, n), n + 17 * dtype, cdt)
+        ref = np.fft.fft(x.astype(np.complex128))
+        d = torch.from_numpy(x).cuda()
+        with fa.Plan(n, batch=batch, dtype=dtype) as p:
+            p.exec(d, d, stream=stream)
+            torch.cuda.synchronize()
+        assert rel_l2(d.cpu().numpy(), ref) < TOL[dtype], (n, batch)
+    # windowed in place
+    n, batch = 2048, 9
+    x = _rand((batch, n), 5, cdt)
+    d = torch.from_numpy(x).cuda()
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.HANN) as p:
+        p.exec(d, d, stream=stream)
+        torch.cuda.synchronize()
+    assert rel_l2(d.cpu().numpy(), np.fft.fft(x.astype(np.complex128) * np.hanning(n))) < TOL[dtype]
