@@ -39,11 +39,16 @@ def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int, device=No
             plan.destroy()
             return other
         _cache[key] = plan
-        while len(_cache) > _CACHE_MAX:
-            _, old = _cache.popitem(last=False)
-            if old is not None:
-                old.destroy()
+        _evict()
     return plan
+
+
+def _evict():
+    """Drop the least recently used plans (cache lock held).  A dropped plan is not destroyed
+    here: another thread may be executing it; it frees its device memory when the last reference
+    goes (Plan.__del__)."""
+    while len(_cache) > _CACHE_MAX:
+        _cache.popitem(last=False)
 
 
 def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
@@ -65,10 +70,7 @@ def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
                 plan.destroy()
             return other
         _cache[key] = plan
-        while len(_cache) > _CACHE_MAX:
-            _, old = _cache.popitem(last=False)
-            if old is not None:
-                old.destroy()
+        _evict()
     return plan
 
 
@@ -87,11 +89,9 @@ def _column_shape(shape, axis, n):
 
 
 def clear_plan_cache():
+    """Forget every cached plan; each frees its device memory once no caller holds it any more."""
     with _cache_lock:
-        while _cache:
-            _, p = _cache.popitem()
-            if p is not None:
-                p.destroy()
+        _cache.clear()
 
 
 def engine_dtype(a: np.ndarray):

@@ -315,3 +315,39 @@ def test_non_finite_samples_behave_like_the_reference(fa):
     x[2, 100] = np.nan
     y = fa.fft(x)
     assert np.all(np.isnan(y[2])) and rel_l2(y[[0, 1, 3]], np.fft.fft(x[[0, 1, 3]].astype(np.complex128))) < 1e-5
+
+
+def test_plan_cache_eviction_while_in_use(fa, monkeypatch):
+    """A plan evicted from the shared cache by another session must stay usable for the thread
+    that is executing it (it is released when its last user lets go, not on eviction)."""
+    import threading
+    from fft_amd import npfft
+    monkeypatch.setattr(npfft, "_CACHE_MAX", 2)
+    npfft.clear_plan_cache()
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((64, 4096)) + 1j * rng.standard_normal((64, 4096)))
+    ref = np.fft.fft(x)
+    errors, stop = [], threading.Event()
+
+    def user():
+        try:
+            plan = npfft.cached_plan(4096, 4096, 64, fa.C128, 0)
+            for _ in range(60):
+                if rel_l2(plan.exec_host(x), ref) > 1e-12:
+                    errors.append("wrong result")
+        except Exception as e:                                        # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            stop.set()
+
+    def churn():
+        k = 0
+        while not stop.is_set():
+            npfft.cached_plan(256 + 16 * (k % 40), 256 + 16 * (k % 40), 1, fa.C128, 0)
+            k += 1
+
+    threads = [threading.Thread(target=user), threading.Thread(target=churn)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    npfft.clear_plan_cache()
+    assert not errors, errors
