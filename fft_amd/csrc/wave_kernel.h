@@ -21,6 +21,10 @@
 #pragma once
 #include "lds_kernel.h"
 
+#ifndef MFFT_WAVE_UNROLL
+#define MFFT_WAVE_UNROLL 4     // 1-KiB steps a wave keeps in flight per loop trip
+#endif
+
 namespace mfft {
 
 template <typename T> struct WaveArgs {
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs<T> a)
 template <typename T, int LOG2N, bool WIN, bool POWER, bool REAL = false>
 int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
 {
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = MFFT_WAVE_UNROLL;
     auto kern = fft_wave_kernel<T, LOG2N, UNROLL, WIN, POWER, REAL>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
