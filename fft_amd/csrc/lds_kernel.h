@@ -45,7 +45,7 @@
 #define MFFT_FAST_BUF 0      // tuning aid: 1 = buffer-resource accesses (scalar offsets) in the plain / hann+power variants
 #endif
 #ifndef MFFT_WIN_BUF_FROM
-#define MFFT_WIN_BUF_FROM 16384
+#define MFFT_WIN_BUF_FROM 16384   // windowed fast variants read the window through a descriptor from this length on
 #endif
 #ifndef MFFT_P8192
 #define MFFT_P8192 32        // points per thread of the 8192-point complex64 kernels (16 or 32)
@@ -68,10 +68,11 @@ namespace mfft {
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
 enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2, WIN_BUF = 3 };
 
-// Waves per SIMD the register allocator must leave room for (1 = no constraint).  The 8192-point
-// complex64 kernel (512 threads, 68 KiB of LDS) fits two workgroups per CU only at <= 128 VGPRs;
-// holding the plain variants there is worth +9..14 % (3.7 -> 4.05..4.3 TB/s); every other size and the
-// general variants (which then spill) measured slower when capped.
+// Waves per SIMD the register allocator must leave room for (1 = no constraint).  In its
+// 16-point-per-thread form (MFFT_P8192 = 16) the 8192-point complex64 kernel (512 threads, 68 KiB of
+// LDS) fits two workgroups per CU only at <= 128 VGPRs; holding the plain variants there is worth
+// +9..14 % (3.7 -> 4.05..4.3 TB/s).  Every other size, the general variants (which then spill) and
+// the default 32-point form measured slower when capped.
 template <typename T, int N, int VAR> constexpr int min_waves_per_eu()
 {
 #if MFFT_WAVES_PER_EU > 0
