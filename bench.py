@@ -307,6 +307,16 @@ def main():
                      "kernel_ms_avg": kern_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    # the timed launches' own output, 64 sampled signals (first, last and a spread over the whole
+    # batch, so every trip of the persistent workgroups is represented) against the CPU oracle
+    rows = np.unique(np.concatenate(([0, batch - 1], np.linspace(0, batch - 1, 62).astype(np.int64))))
+    got = d_s[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
+    from oracle import spectral_oracle as so
+    _, ref = so.windowed_power(x_host[rows], use_hann=True, dt=DT, engine="numpy")
+    line["verified_rel_l2"] = float(np.max(np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)))
+    line["verified_rows"] = int(rows.size)
+    if not line["verified_rel_l2"] < 1e-5:
+        raise SystemExit(f"bench output fails parity with the oracle: rel L2 {line['verified_rel_l2']:.3e}")
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(x_host, n)
         line["cpu_baseline_multicore"] = cpu_multicore(x_host, n)

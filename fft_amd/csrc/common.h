@@ -79,7 +79,7 @@ enum Variant {
     V_REAL = 7,        // real in (full length, contiguous) -> scaled complex out
     V_HANN_POWER_STATS = 8,   // V_HANN_POWER + per-signal max / sum / centroid (the apps' own flag set)
     V_POW_STATS = 9,   // V_POW + the same statistics
-    V_COUNT = 5
+    V_COUNT = 10
 };
 
 // Description of how one power-of-two length is decomposed inside the LDS kernel.

@@ -1,8 +1,7 @@
-// Butterflies and Stockham index algebra shared by every kernel in mfft.hip.
+// Butterflies and Stockham index algebra shared by every kernel of libmfft.so.
 //
 // Everything here is a pure function of registers: no memory access, no thread
-// ids.  The same templates are compiled for gfx950 device code by hipcc and, for
-// the index-algebra unit test (tests/csrc/emul_stockham.cpp), for the host by g++.
+// ids.  The templates compile for gfx950 device code (hipcc) and for the host.
 #pragma once
 #include <stdint.h>
 

@@ -1321,40 +1321,69 @@ int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t
     if (!d_x || rows < 1 || cols < 1 || r0 < 0 || c0 < 0 || n_total < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
     if (n_total > (int64_t(1) << 31)) { set_error("n_total above 2^31"); return MFFT_E_UNSUPPORTED; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // two-level table: k = hi * 2^lo_bits + lo
-    const int total_bits = ilog2(n_total);
-    const int lo_bits = total_bits / 2;
-    const int64_t lo_n = int64_t(1) << lo_bits;
-    const int64_t hi_n = (n_total + lo_n - 1) / lo_n;
-    std::vector<cx<double>> h((size_t)(lo_n + hi_n));
-    for (int64_t k = 0; k < lo_n; ++k) {
-        long double c, d;
-        unit_root(k, n_total, &c, &d);
-        h[(size_t)k] = cx<double>{(double)c, (double)d};
+    if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("bad dtype"); return MFFT_E_INVALID; }
+    // Two-level table, k = hi * 2^lo_bits + lo, kept per (device, n_total): a job uses one or two
+    // moduli, so the few most recent tables stay on the device and a call is one kernel launch.
+    struct Table { int device = -1; int64_t n = 0; cx<double>* d = nullptr; int lo_bits = 0; uint64_t used = 0; };
+    static std::mutex tab_mu;
+    static Table tabs[8];
+    static uint64_t tick = 0;
+    int device = 0;
+    MFFT_HIP(hipGetDevice(&device));
+    const cx<double>* d_tab = nullptr;
+    int lo_bits = 0;
+    int64_t lo_n = 0;
+    {
+        std::lock_guard<std::mutex> lock(tab_mu);
+        Table* hit = nullptr;
+        Table* victim = &tabs[0];
+        for (Table& t : tabs) {
+            if (t.d && t.device == device && t.n == n_total) { hit = &t; break; }
+            if (t.used < victim->used) victim = &t;
+        }
+        if (!hit) {
+            const int total_bits = ilog2(n_total);
+            const int lb = total_bits / 2;
+            const int64_t ln = int64_t(1) << lb;
+            const int64_t hn = (n_total + ln - 1) / ln;
+            std::vector<cx<double>> h((size_t)(ln + hn));
+            for (int64_t k = 0; k < ln; ++k) {
+                long double c, d;
+                unit_root(k, n_total, &c, &d);
+                h[(size_t)k] = cx<double>{(double)c, (double)d};
+            }
+            for (int64_t k = 0; k < hn; ++k) {
+                long double c, d;
+                unit_root(k * ln, n_total, &c, &d);
+                h[(size_t)(ln + k)] = cx<double>{(double)c, (double)d};
+            }
+            cx<double>* fresh = nullptr;
+            MFFT_HIP(hipMalloc((void**)&fresh, h.size() * sizeof(cx<double>)));
+            const hipError_t e = hipMemcpy(fresh, h.data(), h.size() * sizeof(cx<double>), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(fresh); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
+            if (victim->d) {                      // hipFree waits for kernels that may still read it
+                int prev = device;
+                (void)hipSetDevice(victim->device);
+                (void)hipFree(victim->d);
+                (void)hipSetDevice(prev);
+            }
+            victim->device = device; victim->n = n_total; victim->d = fresh; victim->lo_bits = lb;
+            hit = victim;
+        }
+        hit->used = ++tick;
+        d_tab = hit->d;
+        lo_bits = hit->lo_bits;
+        lo_n = int64_t(1) << lo_bits;
     }
-    for (int64_t k = 0; k < hi_n; ++k) {
-        long double c, d;
-        unit_root(k * lo_n, n_total, &c, &d);
-        h[(size_t)(lo_n + k)] = cx<double>{(double)c, (double)d};
-    }
-    cx<double>* d_tab = nullptr;
-    MFFT_HIP(hipMalloc((void**)&d_tab, h.size() * sizeof(cx<double>)));
-    hipError_t e = hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(cx<double>), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { (void)hipFree(d_tab); return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); }
     int64_t blocks = (rows * cols + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (dtype == MFFT_C64)
         hipLaunchKernelGGL(twiddle_tile_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
                            static_cast<cx<float>*>(d_x), rows, cols, r0, c0, n_total, d_tab, d_tab + lo_n, lo_bits);
-    else if (dtype == MFFT_C128)
+    else
         hipLaunchKernelGGL(twiddle_tile_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
                            static_cast<cx<double>*>(d_x), rows, cols, r0, c0, n_total, d_tab, d_tab + lo_n, lo_bits);
-    else { (void)hipFree(d_tab); set_error("bad dtype"); return MFFT_E_INVALID; }
-    e = hipGetLastError();
-    hipError_t e2 = hipStreamSynchronize(s);   // the table is a temporary of this call
-    (void)hipFree(d_tab);
-    if (e != hipSuccess) return hip_fail(e, "twiddle_tile_kernel", __FILE__, __LINE__);
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }
 
