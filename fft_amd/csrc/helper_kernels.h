@@ -237,6 +237,127 @@ __global__ void __launch_bounds__(256) lsq_normal_kernel(const cx<double>* x, co
     }
 }
 
+// The same normal equations for `batch` signals at once, reduced without atomics: block
+// (bx, row, sig*nchunk + chunk) sums its share of the samples for 16 columns of row `row` of
+// signal `sig` and writes 36 doubles {16 x (re, im) of G, re r, im r, yy, pad} to
+//   partial[(((sig*m + row)*nchunk + chunk)*nblk + bx)*36 ...]        (plain stores)
+// and lsq_final_kernel adds the nblk partials of every value in a fixed order, so results do
+// not depend on scheduling.  E holds m line positions per signal, mu one shift per signal (or
+// nullptr), times and win are shared by all signals.
+constexpr int kLsqCols = 16;
+constexpr int kLsqSlot = 2 * kLsqCols + 4;
+struct LsqBatchArgs {
+    const cx<double>* x;      // batch * n samples
+    const double* win;        // n, or nullptr
+    const double* times;      // n
+    const double* mu;         // batch, or nullptr
+    const double* E;          // batch * m
+    double* partial;
+    int64_t n;
+    int m, nchunk, nblk;
+};
+
+__global__ void __launch_bounds__(256) lsq_partial_kernel(const LsqBatchArgs a)
+{
+    __shared__ double red[4][kLsqSlot];
+    const int row = blockIdx.y;
+    const int sig = blockIdx.z / a.nchunk, chunk = blockIdx.z - sig * a.nchunk;
+    const int c0 = chunk * kLsqCols;
+    const int nc = a.m - c0 < kLsqCols ? a.m - c0 : kLsqCols;
+    const double* E = a.E + (size_t)sig * a.m;
+    const double e_row = E[row];
+    double e_col[kLsqCols];
+#pragma unroll
+    for (int b = 0; b < kLsqCols; ++b) e_col[b] = E[c0 + (b < nc ? b : 0)];
+    const double mu = a.mu ? a.mu[sig] : 0.0;
+    const bool rhs = chunk == 0;
+    const cx<double>* x = a.x + (size_t)sig * a.n;
+    double gr[kLsqCols], gi[kLsqCols];
+#pragma unroll
+    for (int b = 0; b < kLsqCols; ++b) { gr[b] = 0.0; gi[b] = 0.0; }
+    double rr = 0.0, ri = 0.0, yy = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += (int64_t)gridDim.x * blockDim.x) {
+        const double t = a.times[j];
+        const double w = a.win ? a.win[j] : 1.0;
+        double sa, ca;
+        sincos(e_row * t, &sa, &ca);                  // conj(b_row) = w (ca + i sa)
+        const double ar = w * ca, ai = w * sa;
+#pragma unroll
+        for (int b = 0; b < kLsqCols; ++b) {
+            if (b < nc) {
+                double sb, cb;
+                sincos(e_col[b] * t, &sb, &cb);       // b_col = w (cb - i sb)
+                const double br = w * cb, bi = -w * sb;
+                gr[b] += ar * br - ai * bi;
+                gi[b] += ar * bi + ai * br;
+            }
+        }
+        if (rhs) {
+            cx<double> y = x[j];
+            y.x *= w; y.y *= w;
+            if (mu != 0.0) {
+                double sm, cm;
+                sincos(mu * t, &sm, &cm);
+                y = cx<double>{y.x * cm - y.y * sm, y.x * sm + y.y * cm};
+            }
+            rr += ar * y.x - ai * y.y;
+            ri += ar * y.y + ai * y.x;
+            yy += y.x * y.x + y.y * y.y;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int b = 0; b < kLsqCols; ++b) { gr[b] += __shfl_xor(gr[b], o, 64); gi[b] += __shfl_xor(gi[b], o, 64); }
+        rr += __shfl_xor(rr, o, 64);
+        ri += __shfl_xor(ri, o, 64);
+        yy += __shfl_xor(yy, o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int b = 0; b < kLsqCols; ++b) { red[wave][2 * b] = gr[b]; red[wave][2 * b + 1] = gi[b]; }
+        red[wave][2 * kLsqCols] = rr;
+        red[wave][2 * kLsqCols + 1] = ri;
+        red[wave][2 * kLsqCols + 2] = yy;
+        red[wave][2 * kLsqCols + 3] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < kLsqSlot) {
+        const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        a.partial[((((size_t)sig * a.m + row) * a.nchunk + chunk) * a.nblk + blockIdx.x) * kLsqSlot + threadIdx.x] = v;
+    }
+}
+
+// out[sig] = {G (2*m*m, row-major, re/im interleaved), r (2*m), yy}: every value is the sum of its
+// nblk partials in block order, and every value of `out` is written exactly once.
+__global__ void __launch_bounds__(256) lsq_final_kernel(const double* partial, double* out, int batch, int m, int nchunk,
+                                                        int nblk)
+{
+    const int64_t total = (int64_t)batch * m * nchunk * kLsqSlot;
+    const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % kLsqSlot);
+        const int64_t q = i / kLsqSlot;                 // (sig*m + row)*nchunk + chunk
+        const int chunk = (int)(q % nchunk);
+        const int64_t sr = q / nchunk;
+        const int row = (int)(sr % m);
+        const int64_t sig = sr / m;
+        const int c0 = chunk * kLsqCols;
+        const int nc = m - c0 < kLsqCols ? m - c0 : kLsqCols;
+        double* o = out + (size_t)sig * nres;
+        double* dst = nullptr;
+        if (v < 2 * nc) dst = o + 2 * ((size_t)row * m + c0) + v;
+        else if (chunk == 0 && (v == 2 * kLsqCols || v == 2 * kLsqCols + 1)) dst = o + 2 * (size_t)m * m + 2 * row + (v - 2 * kLsqCols);
+        else if (chunk == 0 && row == 0 && v == 2 * kLsqCols + 2) dst = o + nres - 1;
+        if (!dst) continue;
+        const double* p = partial + (size_t)q * nblk * kLsqSlot + v;
+        double sum = 0.0;
+        for (int b = 0; b < nblk; ++b) sum += p[(size_t)b * kLsqSlot];
+        *dst = sum;
+    }
+}
+
 // f[j] = sum_k vrow[k] * (exp(-i w[k] t_j / hbar) * c0[k]); the small per-block constants
 // travel in the kernel argument buffer
 struct AmpArgs {

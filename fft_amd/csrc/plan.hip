@@ -115,6 +115,13 @@ int pick_grid(int per_cu, int64_t groups)
 #include "helper_kernels.h"
 #include "copy_pool.h"
 
+// Device scratch of the entry point that allocates nothing (mfft_lsq_normal_static): per-block
+// partial sums of the normal equations.  One copy per GPU the library runs on, held until the
+// process ends.  In host code this name is only a handle for hipGetSymbolAddress -- kernels get
+// the per-device address resolved in static_scratch().
+constexpr size_t kScratchDoubles = size_t(1) << 18;          // 2 MiB
+static __device__ __align__(256) double scratch[kScratchDoubles];
+
 namespace mfft {
 
 // ---------------------------------------------------------------------------
@@ -1180,6 +1187,64 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
     memcpy(h_G, res, 2 * (size_t)m * m * sizeof(double));
     memcpy(h_r, res + 2 * (size_t)m * m, 2 * (size_t)m * sizeof(double));
     *h_yy = res[nres - 1];
+    return MFFT_OK;
+}
+
+// address of `scratch` on the current device, resolved once per device
+static int static_scratch(double** out)
+{
+    static std::mutex mu;
+    static double* ptr[64] = {};
+    int device = 0;
+    MFFT_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64) { set_error("device index out of range"); return MFFT_E_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[device]) {
+        void* p = nullptr;
+        MFFT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { set_error("hipGetSymbolAddress returned a null address"); return MFFT_E_HIP; }
+        ptr[device] = static_cast<double*>(p);
+    }
+    *out = ptr[device];
+    return MFFT_OK;
+}
+
+int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n, int64_t batch,
+                           const double* d_mu, const double* d_E, int m, double* d_out, void* stream)
+{
+    if (!d_x || !d_times || !d_E || !d_out || n < 1 || batch < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (m < 1 || m > 64) { set_error("1 <= m <= 64 columns"); return MFFT_E_INVALID; }
+    if (n > (int64_t(1) << 40)) { set_error("n above 2^40 samples"); return MFFT_E_INVALID; }
+    const int nchunk = (m + kLsqCols - 1) / kLsqCols;
+    // partial sums: batch * m * nchunk * nblk slots of kLsqSlot doubles, inside the fixed scratch
+    const size_t per_blk = (size_t)batch * (size_t)m * (size_t)nchunk * kLsqSlot;
+    if (per_blk > kScratchDoubles || batch * (int64_t)nchunk > 65535) {
+        set_error("mfft_lsq_normal_static: batch * m * ceil(m/16) * 36 doubles exceed the 2 MiB scratch (" +
+                  std::to_string(per_blk * sizeof(double)) + " bytes needed per sample block); split the batch");
+        return MFFT_E_UNSUPPORTED;
+    }
+    int64_t nblk = (n + 255) / 256;
+    if (nblk > 64) nblk = 64;
+    if ((size_t)nblk > kScratchDoubles / per_blk) nblk = (int64_t)(kScratchDoubles / per_blk);
+    double* d_scratch = nullptr;
+    const int rc = static_scratch(&d_scratch);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LsqBatchArgs a;
+    a.x = static_cast<const cx<double>*>(d_x);
+    a.win = d_win; a.times = d_times; a.mu = d_mu; a.E = d_E;
+    a.partial = d_scratch;
+    a.n = n; a.m = m; a.nchunk = nchunk; a.nblk = (int)nblk;
+    // every partial slot that lsq_final_kernel reads is written by exactly one block of this launch,
+    // so nothing in the scratch has to start at zero and no stale value of an earlier call is read
+    hipLaunchKernelGGL(lsq_partial_kernel, dim3((unsigned)nblk, (unsigned)m, (unsigned)(batch * nchunk)), dim3(256), 0, s, a);
+    MFFT_HIP(hipGetLastError());
+    const int64_t total = (int64_t)per_blk;
+    int64_t fblocks = (total + 255) / 256;
+    if (fblocks > 1024) fblocks = 1024;
+    hipLaunchKernelGGL(lsq_final_kernel, dim3((unsigned)fblocks), dim3(256), 0, s, (const double*)d_scratch, d_out,
+                       (int)batch, m, nchunk, (int)nblk);
+    MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }
 

@@ -165,6 +165,25 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
 int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_times, int64_t n,
                          double mu, const double* h_E, int m, double* h_G, double* h_r, double* h_yy);
 
+/* The same normal equations for `batch` signals in one call, on DEVICE arrays, by an entry
+ * point that allocates nothing.  No counterpart in the reference: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation -- and for the batched estimator, which keeps every block's f(t) on the
+ * device.  d_x: batch*n complex128 samples; d_win: n doubles or NULL; d_times: n doubles (shared
+ * by all signals); d_mu: batch doubles or NULL (no demodulation); d_E: batch*m line positions;
+ * d_out: batch * (2*m*m + 2*m + 1) doubles, per signal {G, r, yy} laid out as above.  Every value
+ * of d_out is written (it need not be cleared).  Asynchronous on `stream`.
+ * The per-block partial sums live in a fixed 2 MiB device array inside the library (one per GPU,
+ * held until the process ends), so a call is refused with MFFT_E_UNSUPPORTED when
+ * batch * m * ceil(m/16) * 36 doubles exceed it (m = 6: 1213 signals; m = 64: 28); split larger
+ * batches.  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
+ * two threads) race -- serialise them.  The first call on each device resolves the array's
+ * address and should be made outside graph capture.  Results are deterministic (fixed summation
+ * order, no atomics) and agree with mfft_lsq_normal_host to rounding (1e-13 relative). */
+int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n,
+                           int64_t batch, const double* d_mu, const double* d_E, int m, double* d_out,
+                           void* stream);
+
 /* ---- input generator -----------------------------------------------------------
  * Return amplitude of a small Hermitian block on a time grid,
  *     f[j] = sum_k vrow[k] * ( exp(-i * w[k] * t_j / hbar) * c0[k] ),   k < nk <= 32
