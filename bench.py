@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short timings of BASELINE configs 3-5 (one GPU) appended as `other_configs`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--no-dist-configs", action="store_true",
+                    help="with several ranks: skip the sharded 2-D / long 1-D transforms (BASELINE configs 4, 5) "
+                         "that follow the batch-sharded headline")
+    ap.add_argument("--dist-n2d", type=int, default=16384, help="side of the sharded 2-D transform (config 4)")
+    ap.add_argument("--dist-log2n1d", type=int, default=0,
+                    help="log2 length of the sharded 1-D transform (config 5); 0 = 31 on 8 ranks, else 28 + log2(ranks)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="all ranks share cuda:0 (use with --backend gloo on a one-GPU box; not a measurement)")
     return ap.parse_args()
@@ -181,27 +187,203 @@ def secondary_configs(with_cpu):
     torch.cuda.empty_cache()
     try:
         free, _ = torch.cuda.mem_get_info()
-        lg = 31 if free >= 180 * (1 << 30) else 28
-        n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
-        x = torch.empty(n1 * n2, dtype=torch.complex128, device="cuda")
-        xr = torch.view_as_real(x)
-        for lo in range(0, n1 * n2, 1 << 27):
-            xr[lo:lo + (1 << 27)].normal_()
-        t = timed(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True), 1)
-        out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5,
-                                                          route="four-step decomposition, one rank")
-        ops.close()
-        torch.cuda.empty_cache()
-        # the same transform as ONE plan (four global passes, natural order, no re-layout pass): what a
-        # single GPU should run; the four-step route above is the one-rank case of the multi-GPU path
-        y = torch.empty_like(x)
-        plan = fft_amd.Plan(n1 * n2, dtype=fft_amd.C128)
-        t = timed(lambda: plan.exec(x, y, stream=stream), 1)
-        out[f"config5_1d_2pow{lg}_c128_one_gpu_single_plan"] = entry(t, n1 * n2, lg, 16, launches=plan.launches)
-        plan.destroy()
-        del x, xr, y
+        top = 31 if free >= 180 * (1 << 30) else 28
+        # the shorter lengths are what 2- and 4-GPU jobs run (2^(28 + log2 ranks)): their one-GPU figures
+        for lg in [q for q in (28, 29, 30) if q < top] + [top]:
+            n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+            x = torch.empty(n1 * n2, dtype=torch.complex128, device="cuda")
+            xr = torch.view_as_real(x)
+            for lo in range(0, n1 * n2, 1 << 27):
+                xr[lo:lo + (1 << 27)].normal_()
+            t = timed(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True), 1)
+            out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5,
+                                                              route="four-step decomposition, one rank")
+            ops.close()
+            torch.cuda.empty_cache()
+            if lg == top:
+                # the same transform as ONE plan (global passes, natural order, no re-layout pass): what a
+                # single GPU should run; the four-step route above is the one-rank case of the multi-GPU path
+                y = torch.empty_like(x)
+                plan = fft_amd.Plan(n1 * n2, dtype=fft_amd.C128)
+                t = timed(lambda: plan.exec(x, y, stream=stream), 1)
+                out[f"config5_1d_2pow{lg}_c128_one_gpu_single_plan"] = entry(t, n1 * n2, lg, 16, launches=plan.launches)
+                plan.destroy()
+                del y
+            del x, xr
+            torch.cuda.empty_cache()
     except Exception as exc:                                  # noqa: BLE001
         out["config5_1d_c128_one_gpu"] = {"error": repr(exc)[:200]}
+    ops.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def dist_configs(args, world, rank):
+    """BASELINE configs 4 and 5 over the ranks of this job -- the sharded transforms with real
+    exchange steps (fft_amd/dist.py: row/column slabs with one or two all-to-alls; the four-step
+    split of one long signal with two or three).  Every entry: ms per transform (max over ranks,
+    barrier-bracketed, best of a few brackets), whole-job GFLOP/s, the duration of each exchange
+    on this rank (events around each collective / chunked exchange), the ratio to the one-GPU
+    figure of the same transform when profiles/one_gpu_reference.json has one, and a correctness
+    check of sampled bins against the DFT evaluated directly in float64 over all ranks' data."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from fft_amd import dist as fd
+
+    comm, ops = fd.Comm(), fd.HipOps()
+    P = comm.world
+    out = {"world_size": P, "backend": comm.backend, "transport": "RCCL" if comm.backend == "nccl" else comm.backend,
+           "chunks_first_exchange": fd._chunk_count(None, 1 << 20, P)}
+    one_gpu = {}
+    rpath = os.path.join(ROOT, "profiles", "one_gpu_reference.json")
+    if os.path.exists(rpath):
+        with open(rpath) as fh:
+            one_gpu = json.load(fh)
+
+    def allsum(t):
+        """sum of a small float64 tensor over the ranks (on the host for backends without device support)"""
+        if P == 1:
+            return t
+        if comm.backend == "nccl":
+            dist.all_reduce(t)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c)
+        return c.to(t.device)
+
+    def bracket(fn, inner, reps):
+        fn()
+        torch.cuda.synchronize()
+        best, best_ex = float("inf"), []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            if P > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(inner):
+                comm.timings = [] if i == inner - 1 else None
+                fn()
+            torch.cuda.synchronize()
+            if P > 1:
+                dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / inner], dtype=torch.float64, device="cuda")
+            if P > 1:
+                tc = t if comm.backend == "nccl" else t.cpu()
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+                t = tc
+            ex = [{"exchange": lab, "ms": e0.elapsed_time(e1)} for lab, e0, e1 in (comm.timings or [])]
+            comm.timings = None
+            if float(t.item()) < best:
+                best, best_ex = float(t.item()), ex
+        return best, best_ex
+
+    def entry(t, ex, points, log2n, esz, key, **extra):
+        gf = 5.0 * points * log2n / t / 1e9
+        ref = one_gpu.get(key)
+        d = {"ms": t * 1e3, "gflops": gf, "gbs_algorithmic": 2.0 * esz * points / t / 1e9,
+             "roofline_frac_of_all_gpus": 2.0 * esz * points / t / 1e9 / (HBM_PEAK_GBS * P),
+             "exchanges_rank0": ex, "one_gpu_gflops": ref.get("gflops") if ref else None,
+             "speedup_vs_one_gpu": gf / ref["gflops"] if ref else None}
+        d.update(extra)
+        return d
+
+    # ---- config 4: 2-D complex64, row slabs -------------------------------------------------
+    try:
+        n = args.dist_n2d
+        R, W = n // P, n // P
+        g = torch.Generator(device="cuda").manual_seed(40 + rank)
+        a = torch.view_as_complex(torch.randn((R * n, 2), dtype=torch.float32, device="cuda", generator=g))
+        a2 = a.view(R, n)
+        energy = allsum(torch.sum(torch.view_as_real(a).double() ** 2).reshape(1))
+        rms = math.sqrt(float(energy.item()))
+        j = torch.arange(n, dtype=torch.int64, device="cuda")
+        bins = [(0, 0), (1, 0), (0, 1), (n // 2 - 1, n // 2), (n - 1, n - 1), (12345 % n, 6789 % n), (n // 4, 1), (1, n // 4)]
+
+        def direct(k0, k1):
+            w1 = torch.exp(-2j * math.pi * ((j * k1) % n).double() / n)
+            w0 = torch.exp(-2j * math.pi * ((j[rank * R:(rank + 1) * R] * k0) % n).double() / n)
+            acc = torch.zeros((), dtype=torch.complex128, device="cuda")
+            for lo in range(0, R, 2048):
+                acc = acc + torch.dot(w0[lo:lo + 2048], a2[lo:lo + 2048].to(torch.complex128) @ w1)
+            return acc
+
+        want = allsum(torch.view_as_real(torch.stack([direct(k0, k1) for k0, k1 in bins])).contiguous())
+        for restore in (False, True):
+            f = fd.fft2_slab(a, n, n, comm, ops, restore_layout=restore)
+            got = torch.zeros(len(bins), dtype=torch.complex128, device="cuda")
+            for i, (k0, k1) in enumerate(bins):
+                if restore and k0 // R == rank:
+                    got[i] = f[(k0 - rank * R) * n + k1]
+                if not restore and k1 // W == rank:
+                    got[i] = f[k0 * W + (k1 - rank * W)]
+            got = allsum(torch.view_as_real(got).contiguous())
+            err = float(torch.max(torch.linalg.vector_norm(got - want, dim=-1)).item()) / rms
+            del f
+            t, ex = bracket(lambda: fd.fft2_slab(a, n, n, comm, ops, restore_layout=restore), inner=5, reps=3)
+            name = f"config4_2d_{n}x{n}_c64" + ("_row_slabs_out" if restore else "_column_slabs_out")
+            out[name] = entry(t, ex, n * n, 2 * math.log2(n), 8, f"config4_2d_{n}", scaling="strong",
+                              all_to_alls=2 if restore else 1, verified_max_err_over_rms=err, verified_bins=len(bins))
+            if not err < 1e-5:
+                out[name]["error"] = "sampled bins disagree with the direct DFT"
+        del a, a2
+    except Exception as exc:                                  # noqa: BLE001 - never sink the headline
+        out["config4_error"] = repr(exc)[:300]
+    ops.close()
+    torch.cuda.empty_cache()
+
+    # ---- config 5: one long complex128 signal, four-step ----------------------------------------
+    try:
+        lg = args.dist_log2n1d or (31 if P >= 8 else 28 + int(round(math.log2(P))))
+        n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+        n = n1 * n2
+        cnt = n // P
+        g = torch.Generator(device="cuda").manual_seed(50 + rank)
+        x = torch.empty(cnt, dtype=torch.complex128, device="cuda")
+        xr = torch.view_as_real(x)
+        for lo in range(0, cnt, 1 << 26):
+            xr[lo:lo + (1 << 26)].normal_(generator=g)
+        e_loc = 0.0
+        for lo in range(0, cnt, 1 << 26):
+            e_loc += float(torch.sum(xr[lo:lo + (1 << 26)] ** 2).item())
+        rms = math.sqrt(float(allsum(torch.tensor([e_loc], dtype=torch.float64, device="cuda")).item()))
+        ks = [0, 1, n1 - 1, n1, n // 2 - 1, n // 2, n - n2, n - 1, 1234567891 % n, 987654321 % n]
+
+        def direct1(k):
+            acc = torch.zeros((), dtype=torch.complex128, device="cuda")
+            for lo in range(0, cnt, 1 << 25):
+                hi = min(cnt, lo + (1 << 25))
+                jj = torch.arange(rank * cnt + lo, rank * cnt + hi, dtype=torch.int64, device="cuda")
+                ang = -2.0 * math.pi * (((jj * int(k)) % n).double() / n)          # exact: j*k < 2^62
+                acc = acc + torch.sum(x[lo:hi] * torch.complex(torch.cos(ang), torch.sin(ang)))
+                del jj, ang
+            return acc
+
+        want = allsum(torch.view_as_real(torch.stack([direct1(k) for k in ks])).contiguous())
+        for natural in (True, False):
+            y = fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=natural)
+            got = torch.zeros(len(ks), dtype=torch.complex128, device="cuda")
+            for i, k in enumerate(ks):
+                if natural:
+                    if k // cnt == rank:
+                        got[i] = y[k - rank * cnt]
+                else:                                   # out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2]
+                    k1, k2 = k % n1, k // n1
+                    if k1 // (n1 // P) == rank:
+                        got[i] = y[(k1 - rank * (n1 // P)) * n2 + k2]
+            got = allsum(torch.view_as_real(got).contiguous())
+            err = float(torch.max(torch.linalg.vector_norm(got - want, dim=-1)).item()) / rms
+            del y
+            t, ex = bracket(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=natural), inner=2, reps=2)
+            name = f"config5_1d_2pow{lg}_c128" + ("_natural_order" if natural else "_transposed_order")
+            out[name] = entry(t, ex, n, lg, 16, f"config5_1d_2pow{lg}", scaling="strong",
+                              all_to_alls=3 if natural else 2, verified_max_err_over_rms=err, verified_bins=len(ks))
+            if not err < 1e-12:
+                out[name]["error"] = "sampled bins disagree with the direct DFT"
+        del x, xr
+    except Exception as exc:                                  # noqa: BLE001
+        out["config5_error"] = repr(exc)[:300]
     ops.close()
     torch.cuda.empty_cache()
     return out
@@ -327,6 +509,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and n == N_POINTS and batch == BATCH:
         torch.cuda.empty_cache()
         line["other_configs"] = secondary_configs(with_cpu=not args.no_cpu)
+    if distributed and not args.no_dist_configs:
+        # every rank takes part; rank 0 reports
+        torch.cuda.empty_cache()
+        dc = dist_configs(args, world, rank)
+        if rank == 0:
+            line["dist_configs"] = dc
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:

@@ -55,14 +55,34 @@ class Comm:
             self.backend = dist.get_backend(group)
         else:
             self.world, self.rank, self.backend = 1, 0, "none"
+        # When set to a list, every exchange appends (label, start event, end event) recorded on
+        # the current stream (device tensors only): per-exchange times for the benchmark.
+        self.timings = None
 
-    def all_to_all(self, dst, src):
+    def _mark(self, like):
+        if self.timings is None or not getattr(like, "is_cuda", False):
+            return None
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def all_to_all(self, dst, src, label="all_to_all"):
         """Exchange equal chunks: the r-th chunk of the result is rank r's src[my chunk].
         Returns the tensor that holds the result -- `dst`, or `src` itself when there is only
         one rank (no copy); the other one is free for reuse by the caller."""
         import torch
         if self.world == 1:
             return src
+        e0 = self._mark(src)
+        try:
+            return self._all_to_all(dst, src)
+        finally:
+            if e0 is not None:
+                self.timings.append((label, e0, self._mark(src)))
+
+    def _all_to_all(self, dst, src):
+        import torch
         d, s = torch.view_as_real(dst), torch.view_as_real(src)
         if self.backend == "gloo" and src.is_cuda:
             # rehearsal mode (several ranks sharing one GPU box): stage through the host
@@ -75,7 +95,7 @@ class Comm:
         return dst
 
 
-    def start_exchange(self, send_blocks, recv_blocks):
+    def start_exchange(self, send_blocks, recv_blocks, label="exchange"):
         """Begin a personalised exchange of contiguous blocks: send_blocks[s] goes to rank s and
         recv_blocks[r] receives what rank r sends here (the own block is copied locally).  Returns
         a handle whose wait() completes it.  Point-to-point sends and receives in one group (what an
@@ -83,6 +103,7 @@ class Comm:
         transforming the next while it is on the links."""
         import torch
         dist = self._dist
+        e0 = self._mark(send_blocks[0])
         recv_blocks[self.rank].copy_(send_blocks[self.rank])
         if self.world == 1:
             return _Exchange([], [])
@@ -101,19 +122,24 @@ class Comm:
                 rcv = tmp
             ops.append(dist.P2POp(dist.isend, snd, dst_rank, self.group))
             ops.append(dist.P2POp(dist.irecv, rcv, dst_rank, self.group))
-        return _Exchange(dist.batch_isend_irecv(ops), post)
+        done = None
+        if e0 is not None:
+            done = lambda: self.timings.append((label, e0, self._mark(send_blocks[0])))   # noqa: E731
+        return _Exchange(dist.batch_isend_irecv(ops), post, done)
 
 
 class _Exchange:
-    def __init__(self, works, post):
-        self._works, self._post = works, post
+    def __init__(self, works, post, done=None):
+        self._works, self._post, self._done = works, post, done
 
     def wait(self):
         for w in self._works:
             w.wait()
         for dst, src in self._post:
             dst.copy_(src)
-        self._works, self._post = [], []
+        if self._done is not None:
+            self._done()
+        self._works, self._post, self._done = [], [], None
 
 
 def _chunk_count(requested, rows, world):
@@ -257,7 +283,7 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
     C = _chunk_count(chunks, R, P)
     if C == 1:
         ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
-        cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c]: (n0 x W), row r*R + i, local column c
+        cur = comm.all_to_all(bufs.free(x), x, "rows->columns")     # cur[r][i][c]: (n0 x W), row r*R + i, local column c
     else:
         Rc = R // C
         cur = bufs.free(x)
@@ -267,7 +293,7 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
             ops.fft(a_local[c * Rc * n1:(c + 1) * Rc * n1], sb, n=n1, batch=Rc, out_layout=(W, W, Rc * W))
             sends = [sb[s * Rc * W:(s + 1) * Rc * W] for s in range(P)]
             recvs = [cur[(r * R + c * Rc) * W:(r * R + (c + 1) * Rc) * W] for r in range(P)]
-            pending.append(comm.start_exchange(sends, recvs))
+            pending.append(comm.start_exchange(sends, recvs, f"rows->columns[{c}/{C}]"))
         for h in pending:
             h.wait()
     nxt = bufs.free(cur)
@@ -283,7 +309,7 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
     if not restore_layout:
         return cur
     # rows [s*R, (s+1)*R) belong to rank s: the per-destination chunks are already contiguous
-    res = comm.all_to_all(bufs.free(cur), cur)     # res[s][i][c] = F[rank*R + i][s*W + c]
+    res = comm.all_to_all(bufs.free(cur), cur, "columns->rows")     # res[s][i][c] = F[rank*R + i][s*W + c]
     if P == 1:
         return res
     out = bufs.free(res)
@@ -329,7 +355,7 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
         C = _chunk_count(chunks, R1, P)
         if C == 1:
             ops.swap_axes(x_local, x, a=R1, b=P, w=W2)
-            cur = comm.all_to_all(bufs.free(x), x)     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
+            cur = comm.all_to_all(bufs.free(x), x, "samples->columns")     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
         else:
             Rc = R1 // C
             cur = bufs.free(x)
@@ -339,7 +365,7 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
                 ops.swap_axes(x_local[c * Rc * n2:(c + 1) * Rc * n2], sb, a=Rc, b=P, w=W2)
                 sends = [sb[s * Rc * W2:(s + 1) * Rc * W2] for s in range(P)]
                 recvs = [cur[(r * R1 + c * Rc) * W2:(r * R1 + (c + 1) * Rc) * W2] for r in range(P)]
-                pending.append(comm.start_exchange(sends, recvs))
+                pending.append(comm.start_exchange(sends, recvs, f"samples->columns[{c}/{C}]"))
             for h in pending:
                 h.wait()
     nxt = bufs.free(cur)
@@ -355,7 +381,7 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
         cur = bufs.free(tmp, x_local)
         ops.transpose(tmp, cur, rows=W2, cols=n1)  # (n1 x W2)
     # rows k1 in [s*R1, (s+1)*R1) belong to rank s: chunks already contiguous
-    res = comm.all_to_all(bufs.free(cur, x_local), cur)   # res[s][i][c] = A[k1 = rank*R1 + i][j2 = s*W2 + c]
+    res = comm.all_to_all(bufs.free(cur, x_local), cur, "columns->rows")   # res[s][i][c] = A[k1 = rank*R1 + i][j2 = s*W2 + c]
     out = bufs.free(res, x_local)
     # n2-point FFT over j2 for each local row i: sample j2 sits at [j2 // W2][i][j2 % W2]
     seg_in = (W2, W2, R1 * W2)
@@ -364,7 +390,7 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
         return out
     # bin k2 of local row i goes to [k2 // W2][i][k2 % W2] (owner of natural index k2*n1 + k1)
     ops.fft(res, out, n=n2, batch=R1, in_layout=seg_in, out_layout=seg_in)
-    res = comm.all_to_all(bufs.free(out, x_local), out)   # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
+    res = comm.all_to_all(bufs.free(out, x_local), out, "natural order")   # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
     out = bufs.free(res, x_local)
     ops.transpose(res, out, rows=n1, cols=W2)      # -> (W2 x n1) = natural-order chunk
     return out

@@ -29,11 +29,11 @@ class FakeComm:
         self.exchanges = 0
         self.chunks_seen = 4          # the decompositions' default chunk count with several ranks
 
-    def all_to_all(self, dst, src):
+    def all_to_all(self, dst, src, label=None):
         self.exchanges += 1
         return src
 
-    def start_exchange(self, send_blocks, recv_blocks):
+    def start_exchange(self, send_blocks, recv_blocks, label=None):
         """One chunk of the pipelined first exchange: counted as a fraction of an all-to-all."""
         self.exchanges += 1.0 / self.chunks_seen if self.chunks_seen else 0
 
