@@ -51,8 +51,8 @@
 #define MFFT_P8192 32        // points per thread of the 8192-point complex64 kernels (16 or 32)
 #endif
 #ifndef MFFT_PREFETCH
-#define MFFT_PREFETCH 0      // 1 = wave-private fast variants load the next signal before transforming the current one
-#endif
+#define MFFT_PREFETCH -1     // fast variants load the next signal before transforming the current one: -1 = where measured faster
+#endif                       // (prefetch_default), 0 = never, bit 0 = signals inside one wave, bit 1 = signals spanning several waves
 #ifndef MFFT_TW16_SPLIT
 #define MFFT_TW16_SPLIT 1    // radix-16 passes keep w^1,w^2,w^3,w^4,w^8,w^12 and form the other nine by one multiply
 #endif
@@ -337,6 +337,21 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
     return b;
 }
 
+// Where loading the next signal into registers ahead of the butterflies measured faster (MI355X,
+// 2^26 points per launch).  Signals inside one wave: never (the waves of a workgroup drift apart
+// and overlap loads with butterflies by themselves; 1024 points Hann + power: 139-141 against
+// 134 us).  complex64 2048 points (128-thread workgroups): every fast variant, +2.5 % plain ..
+// +14 % Hann + power; 4096 points: the power-only and statistics variants (+6..7 %) but not the
+// windowed ones (-3..-6 %).  From 8192 points the extra registers spill (8192: 4.7 -> 4.0 TB/s,
+// 16384: 4.1 -> 2.4) and complex128 loses 1..17 % at every length.
+template <typename T, int N, int VAR> constexpr bool prefetch_default()
+{
+    if (sizeof(T) != 4) return false;
+    if (N == 2048) return true;
+    if (N == 4096) return VAR == V_POW || VAR == V_POW_STATS || VAR == V_HANN_POWER_STATS;
+    return false;
+}
+
 template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
 __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
 {
@@ -392,26 +407,11 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     }
 
     const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
-    // Software pipeline (wave-private signals, fast variants): the next signal's loads are issued
-    // before the current one is transformed, so the bus never waits for the butterflies.
-    constexpr bool PREFETCH = MFFT_PREFETCH != 0 && !GENERAL && VAR != V_SEG && TX <= 64;
-    C vn[PREFETCH ? P : 1];
-    if constexpr (PREFETCH) {
-        if ((int64_t)blockIdx.x < groups) {
-            const int64_t b1 = (int64_t)blockIdx.x * SLOTS + slot;
-            const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + (b1 < a.batch ? b1 : a.batch - 1) * a.in_stride;
-#pragma unroll
-            for (int e = 0; e < P; ++e) vn[e] = ld_stream(src + t + TX * e);
-        }
-    }
-    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
-        const int64_t b = g * SLOTS + slot;
-        const bool active = b < a.batch;
-        C v[P];
-
-        // ---- load (pass-0 inputs: positions t + TX*e) ----------------------
+    // Load of one signal in the fast variants (pass-0 inputs: positions t + TX*e).  A slot beyond the
+    // batch re-reads the last signal and skips its stores: no branch here.
+    const auto load_fast = [&](C (&dst)[P], int64_t bsig) {
+        const int64_t bl = bsig < a.batch ? bsig : a.batch - 1;
         if constexpr (VAR == V_SEG) {
-            const int64_t bl = active ? b : a.batch - 1;
             const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
             // segments hold a whole number of TX-element rows (seg = TX << q), so the segment of
             // element t + TX*e is e >> q for every lane: the offsets are wave-uniform (scalar
@@ -420,33 +420,47 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #pragma unroll
             for (int e = 0; e < P; ++e) {
                 const int64_t off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
-                v[e] = ld_stream(src + off + t);
+                dst[e] = ld_stream(src + off + t);
             }
         } else if constexpr (VAR == V_REAL) {
-            const int64_t bl = active ? b : a.batch - 1;
             const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + bl * a.in_stride;
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = C{ld_stream_real(src + t + TX * e), (T)0};
-        } else if constexpr (!GENERAL) {
-            // a slot beyond the batch re-reads the last signal and skips its stores: no branch here
-            const int64_t bl = active ? b : a.batch - 1;
+            for (int e = 0; e < P; ++e) dst[e] = C{ld_stream_real(src + t + TX * e), (T)0};
+        } else {
             const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
             if constexpr (MFFT_FAST_BUF != 0 && TX >= 64) {
                 const auto rs = make_rsrc(src, (uint32_t)N * sizeof(C));
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = buf_ld<C, MFFT_NT ? 2 : 0>(rs, (uint32_t)t * sizeof(C), TX * e * sizeof(C));
-            } else if constexpr (PREFETCH) {
+                for (int e = 0; e < P; ++e) dst[e] = buf_ld<C, MFFT_NT ? 2 : 0>(rs, (uint32_t)t * sizeof(C), TX * e * sizeof(C));
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) dst[e] = ld_stream(src + t + TX * e);
+            }
+        }
+    };
+    // Software pipeline (fast variants): the next signal's loads are issued before the current one
+    // is transformed, so the bus does not idle during the butterflies.
+    constexpr bool PREFETCH = !GENERAL && (MFFT_PREFETCH < 0 ? prefetch_default<T, N, VAR>()
+                                                             : (((MFFT_PREFETCH & 1) != 0 && TX <= 64) || ((MFFT_PREFETCH & 2) != 0 && TX > 64)));
+    C vn[PREFETCH ? P : 1];
+    if constexpr (PREFETCH) {
+        if ((int64_t)blockIdx.x < groups) load_fast(vn, (int64_t)blockIdx.x * SLOTS + slot);
+    }
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t b = g * SLOTS + slot;
+        const bool active = b < a.batch;
+        C v[P];
+
+        // ---- load ----------------------------------------------------------------
+        if constexpr (!GENERAL) {
+            if constexpr (PREFETCH) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = vn[e];
                 // the group after this one (re-reads this one at the end of the batch: no branch)
                 const int64_t gn = g + gridDim.x < groups ? g + gridDim.x : g;
-                const int64_t bn = gn * SLOTS + slot;
-                const C* __restrict__ nsrc = reinterpret_cast<const C*>(a.in) + (bn < a.batch ? bn : a.batch - 1) * a.in_stride;
-#pragma unroll
-                for (int e = 0; e < P; ++e) vn[e] = ld_stream(nsrc + t + TX * e);
+                load_fast(vn, gn * SLOTS + slot);
             } else {
-#pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = ld_stream(src + t + TX * e);
+                load_fast(v, b);
             }
             if constexpr (FASTWIN) {
 #pragma unroll
@@ -712,6 +726,8 @@ template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices
 #endif
 #if MFFT_P16384 == 32
 template <> struct SizeCfg<14> { static constexpr int P = 32; using RD = Radices<32, 16, 32, 1>; };
+#elif MFFT_P16384 == 33     // 32 points per thread, radix-16 butterflies only (smaller working set)
+template <> struct SizeCfg<14> { static constexpr int P = 32; using RD = Radices<4, 16, 16, 16>; };
 #else
 template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices<4, 16, 16, 16>; };
 #endif
