@@ -189,6 +189,7 @@ struct Pow2Engine {
     void* d_wave_tw = nullptr;          // W_N^j, j < N/2, for the lane-distributed kernel (shortest lengths)
     std::vector<GlobalPass> passes;     // tiled decomposition
     void* work[2] = {nullptr, nullptr};
+    size_t work_bytes = 0;
     void* stage_in = nullptr;           // dense copies around a general single-kernel transform whose
     void* stage_out = nullptr;          // caller layout is segmented (allocated on first use)
     int64_t bytes = 0;                  // device memory held
@@ -222,13 +223,20 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
         int sum = 0;
         for (const char* p = env; *p;) {
             const int v = (int)strtol(p, const_cast<char**>(&p), 10);
-            if (v < kTileMinLog2G || v > kTileMaxLog2G) break;
+            if (v < kTileMinLog2G || v > (dtype == MFFT_C64 && !log2_inner ? kTileMaxLog2GNarrow : kTileMaxLog2G)) break;
             out->push_back(v);
             sum += v;
             if (*p == ',') ++p;
         }
         if (sum == log2n && out->size() >= (log2_inner ? 1u : 2u) && out->size() <= 4) return MFFT_OK;
         out->clear();
+    }
+    // 2^19 complex64 points: 1024 x 512 in two passes (four-column first pass, XCD-aware order)
+    // measured 107 us per 2^24 points against 156 us for three passes; the larger narrow radices lost.
+    if (dtype == MFFT_C64 && !log2_inner && log2n == 19 && !getenv("MFFT_NO_NARROW_RADIX")) {
+        out->push_back(10);
+        out->push_back(9);
+        return MFFT_OK;
     }
     const int maxg = kTileMaxLog2G;
     const int npass = (log2n + maxg - 1) / maxg;
@@ -345,9 +353,11 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         int k = 0;
         for (const char* c = env; *c && k < 4; ++c) if (*c >= '0' && *c <= '3') tile_nt_pass[k++] = *c - '0';
     }
-    const int nwork = passes.size() > 2 ? 2 : (passes.size() > 1 ? 1 : 0);
-    for (int i = 0; i < nwork; ++i) {
-        MFFT_HIP(hipMalloc(&work[i], wbytes));
+    // One workspace: the passes alternate between it and the caller's output buffer (see exec); a
+    // second one is allocated on first use by the executions that cannot do that.
+    work_bytes = wbytes;
+    if (passes.size() > 1) {
+        MFFT_HIP(hipMalloc(&work[0], wbytes));
         bytes += (int64_t)wbytes;
     }
     return MFFT_OK;
@@ -461,6 +471,17 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         return MFFT_OK;
     }
     const int np = (int)passes.size();
+    // Intermediate passes ping-pong between the workspace and the output buffer itself when that is
+    // a dense complex array of the transform's size -- pass p writes the output when np - 1 - p is
+    // even -- which halves the workspace and keeps one buffer fewer competing for the Infinity
+    // Cache.  Not possible when the first pass would overwrite its own input (in-place execution of
+    // an odd number of passes) or the output is shorter, strided, segmented or real: two workspaces.
+    bool via_out = np >= 3 && !io.power && io.out_seg == 0 && io.out_stride == n * inner && io.n_out == n &&
+                   !(io.in == io.out && (np & 1)) && !getenv("MFFT_WORK2");
+    if (np >= 3 && !via_out && !work[1]) {
+        MFFT_HIP(hipMalloc(&work[1], work_bytes));
+        bytes += (int64_t)work_bytes;
+    }
     const void* src = io.in;
     int64_t src_stride = io.in_stride;
     const int64_t nn = n * inner;       // elements per transform unit (one signal, or one n x inner array)
@@ -471,7 +492,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         TArgs<T> a{};
         a.in = src;
         a.in_stride = src_stride;
-        a.out = last ? io.out : work[p & 1];
+        a.out = last ? io.out : (via_out ? (((np - 1 - p) & 1) ? work[0] : io.out) : work[p & 1]);
         a.out_stride = last ? io.out_stride : nn;
         a.tw = static_cast<const cx<T>*>(gp.d_tw);
         a.tw_lo = static_cast<const cx<double>*>(gp.d_lo);
@@ -485,6 +506,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.batch = nb;
         a.lb = gp.lb;
         a.nt = (p < 4 && tile_nt_pass[p] >= 0) ? tile_nt_pass[p] : tile_nt;
+        a.xcd = gp.log2g > kTileMaxLog2G ? 1 : 0;       // four-column tiles: neighbours share cache lines,
+        if (a.xcd) a.nt = 0;                             // which streaming accesses would not keep in L2
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;

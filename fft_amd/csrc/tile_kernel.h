@@ -89,6 +89,7 @@ template <typename T> struct TArgs {
     int real_in, conj_in, conj_out;
     int narrow;           // 1: the narrow tile width (see TileCols)
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
+    int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
     T scale;
 };
 
@@ -105,11 +106,22 @@ enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN 
 // TB/s at 256-B runs and ~5.5 TB/s from 512 B; on the transforms wide tiles are worth +5..8 %
 // (complex64, 2^19..2^22 points) and +2..13 % (complex128, every length), while 64 complex64
 // columns at 256 points (one 1024-thread workgroup per CU) lose 6-9 %.
+// Radices 1024, 2048, 4096 (complex64, two-pass plans of 2^19..2^24 points): four columns, i.e.
+// 32-byte rows -- all that fits LDS at 4096 points.  Four neighbouring tiles then share every
+// 128-byte line, which only pays when they run on the same XCD (TArgs::xcd): measured as bare copies
+// of the 4096 x 4 shape, 2.3 TB/s in dispatch order against 5.5 TB/s (strided in, contiguous out)
+// and 1.9 against 4.7 TB/s (strided in and out) with each XCD walking one contiguous tile range.
 template <typename T, int LOG2G, bool NARROW> struct TileCols {
-    static constexpr int WIDE = sizeof(T) == 4 ? (LOG2G <= 7 ? 6 : (LOG2G == 8 ? 5 : 4)) : (LOG2G <= 8 ? 5 : 4);
-    static constexpr int SLIM = (sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0);
+    static constexpr int WIDE = LOG2G >= 10 ? 2 : (sizeof(T) == 4 ? (LOG2G <= 7 ? 6 : (LOG2G == 8 ? 5 : 4)) : (LOG2G <= 8 ? 5 : 4));
+    static constexpr int SLIM = LOG2G >= 10 ? 2 : ((sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0));
     static constexpr int LOG2C = NARROW ? SLIM : WIDE;
 };
+
+// LDS image of a tile: [position][column] with an odd pitch (C + 1) so that lanes along a row and
+// lanes down a column are both conflict-free; four-column tiles keep pitch C (the padded pitch would
+// not fit LDS at 4096 points) and turn their first-pass output through a column-major image instead.
+template <int C> constexpr int tile_pitch() { return C >= 8 ? C + 1 : C; }
+template <int G> constexpr int tile_colpitch() { return lds_pad<kPadShift>(G - 1) + 1 + 8; }   // = 8 mod 32 elements
 
 template <int LOG2G> struct TileCfg {
     using SC = SizeCfg<LOG2G>;
@@ -141,6 +153,9 @@ __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>
     for (int e = 0; e < P; ++e) v[e] = lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)];
 }
 
+#ifndef MFFT_BIG_RADIX
+#define MFFT_BIG_RADIX 0     // 1 = also build the 2048- and 4096-point tile radices (tuning builds; MFFT_SPLIT selects them)
+#endif
 #ifndef MFFT_TILE_OCC
 #define MFFT_TILE_OCC 1      // 1 = hold the plain modes at the VGPR count that lets two workgroups share a CU
 #endif
@@ -167,10 +182,11 @@ fft_tile_kernel(const TArgs<T> a)
     constexpr int G = TC::G, P = TC::P, TX = TC::TX;
     constexpr int C = 1 << LOG2C;
     constexpr int BLOCK = TX * C;
-    constexpr int PITCH = C + 1;
+    constexpr int PITCH = tile_pitch<C>();
     constexpr int PADSHIFT = kPadShift;
     constexpr int NPASS = RD::npass;
-    constexpr int LDS_ELEMS = (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
+    constexpr int COLPITCH = tile_colpitch<G>();
+    constexpr int LDS_ELEMS = PITCH == C ? COLPITCH * C : (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
@@ -184,22 +200,44 @@ fft_tile_kernel(const TArgs<T> a)
     // NS, L and the tile count are powers of two: shifts and masks, no 64-bit division
     const int64_t total = a.batch << a.log2_tiles;
     const int64_t ns_mask = a.NS - 1;
-    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    // Workgroup w runs on XCD w % 8 (round-robin dispatch).  With a.xcd (four-column tiles) every XCD
+    // takes one contiguous range of tiles and walks it in dispatch order, so that neighbouring
+    // tiles, which share cache lines at that width, meet in one L2 instead of eight.
+    constexpr bool SLIM4 = LOG2C <= 2;
+    const bool xcd_map = SLIM4 && a.xcd != 0 && (gridDim.x & 7) == 0 && total >= 64;
+    const int64_t w_off = xcd_map ? (int64_t)(blockIdx.x & 7) * ((total + 7) >> 3) : 0;
+    const int64_t w_end = xcd_map ? ((total + 7) >> 3) : total;
+    const int64_t w_step = xcd_map ? (gridDim.x >> 3) : gridDim.x;
+    for (int64_t wl = xcd_map ? (blockIdx.x >> 3) : blockIdx.x; wl < w_end; wl += w_step) {
+        const int64_t w = w_off + wl;
+        if (SLIM4 && w >= total) break;
         const int64_t b = w >> a.log2_tiles;
         const int64_t j0 = (w & ((int64_t(1) << a.log2_tiles) - 1)) * C;
         const int64_t j = j0 + c;
         C_ v[P];
 
         // ---- load the G x C tile (row i = t + TX*e, column c) --------------------
+        // Four-column tiles address as a wave-uniform 64-bit base (tile origin + e row groups: scalar
+        // registers) plus one 32-bit lane offset (column + t rows), so sixteen accesses cost one address
+        // register (they run in 1024-thread workgroups: 128 VGPRs); they always use plain accesses --
+        // a streaming load would not keep the line for the three neighbours that share it.  Wider
+        // tiles step a per-lane pointer, which measured 2-4 % faster there.
+        const uint32_t lane_in = (uint32_t)c + (uint32_t)t * (uint32_t)a.L;          // < N / P
+        const C_* __restrict__ in_base = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j0;
+        const int64_t pstep = (int64_t)TX * a.L;
         if constexpr (MODE == TM_FIRST_PLAIN) {
-            const C_* __restrict__ p = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j + (int64_t)t * a.L;
-            const int64_t pstep = (int64_t)TX * a.L;
-            if (a.nt & 1) {
+            if constexpr (SLIM4) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+                for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
             } else {
+                const C_* __restrict__ p = in_base + lane_in;
+                if (a.nt & 1) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+                    for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+                }
             }
         } else if constexpr (MODE == TM_FIRST_GEN) {
             // runtime prologue: unconditional loads at clamped indices, options as uniform
@@ -246,16 +284,19 @@ fft_tile_kernel(const TArgs<T> a)
                 if (j + (int64_t)(t + TX * e) * a.L > last) v[e] = C_{0, 0};   // zero padding
             }
         } else {
-            const C_* __restrict__ src = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j;
             const uint32_t m = (uint32_t)((j & ns_mask) >> a.log2_w);   // NS / W <= 2^30
-            const C_* __restrict__ p = src + (int64_t)t * a.L;
-            const int64_t pstep = (int64_t)TX * a.L;
-            if (a.nt & 1) {
+            if constexpr (SLIM4) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+                for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
             } else {
+                const C_* __restrict__ p = in_base + lane_in;
+                if (a.nt & 1) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+                    for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, true>(p); p += pstep; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
+                }
             }
 #if !MFFT_DIAG_NOFFT
             const uint32_t lomask = (1u << a.lb) - 1;
@@ -298,28 +339,41 @@ fft_tile_kernel(const TArgs<T> a)
             // q fastest.  Turn the registers through LDS so that lanes run along q.
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < P; ++e) lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)] = v[e];
+            for (int e = 0; e < P; ++e) {
+                if constexpr (PITCH == C) lds[c * COLPITCH + lds_pad<PADSHIFT>(t + TX * e)] = v[e];
+                else lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)] = v[e];
+            }
             __syncthreads();
             C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j0 * G;
 #pragma unroll
             for (int e = 0; e < P; ++e) {
                 const int r = threadIdx.x + BLOCK * e;      // element of the run: r = cc*G + q
                 const int cc = r / G, q = r % G;
-                const C_ val = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
-                if (a.nt & 2) tile_st<T, true>(dst + r, val);
+                C_ val;
+                if constexpr (PITCH == C) val = lds[cc * COLPITCH + lds_pad<PADSHIFT>(q)];
+                else val = lds[tile_addr<PADSHIFT, PITCH>(q, cc)];
+                if constexpr (SLIM4) tile_st<T, false>(dst + BLOCK * e + threadIdx.x, val);
+                else if (a.nt & 2) tile_st<T, true>(dst + r, val);
                 else tile_st<T, false>(dst + r, val);
             }
         } else if constexpr (MODE == TM_MID) {
-            const int64_t m = j & ns_mask;
-            C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride +
-                                 ((j >> a.log2_ns) << a.log2_ns) * G + m + (int64_t)t * a.NS;
+            // a tile never straddles a block of NS super-butterflies (C <= NS, both powers of two)
+            C_* __restrict__ out_base = reinterpret_cast<C_*>(a.out) + b * a.out_stride +
+                                        ((j0 >> a.log2_ns) << a.log2_ns) * G + (j0 & ns_mask);
+            const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
-            if (a.nt & 2) {
+            if constexpr (SLIM4) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+                for (int e = 0; e < P; ++e) tile_st<T, false>(out_base + e * qstep + lane_out, v[e]);
             } else {
+                C_* __restrict__ q = out_base + lane_out;
+                if (a.nt & 2) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+                    for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+                }
             }
         } else if constexpr (MODE == TM_LAST_TWID) {
             // last pass of a column-batched transform with the four-step twiddle folded in:
@@ -351,14 +405,21 @@ fft_tile_kernel(const TArgs<T> a)
             }
         } else if constexpr (MODE == TM_LAST_PLAIN) {
             // last pass: NS*G = N, so j < NS and bin k = j + q*NS
-            C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j + (int64_t)t * a.NS;
+            C_* __restrict__ out_base = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j0;
+            const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
-            if (a.nt & 2) {
+            if constexpr (SLIM4) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+                for (int e = 0; e < P; ++e) tile_st<T, false>(out_base + e * qstep + lane_out, v[e]);
             } else {
+                C_* __restrict__ q = out_base + lane_out;
+                if (a.nt & 2) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+                    for (int e = 0; e < P; ++e) { tile_st<T, true>(q, v[e]); q += qstep; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) { tile_st<T, false>(q, v[e]); q += qstep; }
+                }
             }
         } else {
             double mx = 0.0, sm = 0.0, sk = 0.0;
@@ -422,7 +483,9 @@ template <typename T, int LOG2G, int LOG2C> constexpr size_t tile_lds_bytes()
 {
     constexpr int G = 1 << LOG2G, C = 1 << LOG2C;
     using RD = typename TileCfg<LOG2G>::SC::RD;
-    return ((size_t)(lds_pad<kPadShift>(G - 1) + 1) * (C + 1) + (size_t)tw_total_elems<RD>()) * sizeof(cx<T>);
+    constexpr size_t image = tile_pitch<C>() == C ? (size_t)tile_colpitch<G>() * C
+                                                  : (size_t)(lds_pad<kPadShift>(G - 1) + 1) * tile_pitch<C>();
+    return (image + (size_t)tw_total_elems<RD>()) * sizeof(cx<T>);
 }
 
 template <typename T, int LOG2G, int LOG2C, int MODE>
@@ -488,8 +551,13 @@ int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
     case 7: return launch_tile_mode<T, 7>(mode, a, s);
     case 8: return launch_tile_mode<T, 8>(mode, a, s);
     case 9: return launch_tile_mode<T, 9>(mode, a, s);
+    case 10: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 10>(mode, a, s); else break;
+#if MFFT_BIG_RADIX      // 2048 and 4096: measured slower than three passes everywhere; kept for the measurement
+    case 11: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 11>(mode, a, s); else break;
+    case 12: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 12>(mode, a, s); else break;
+#endif
     }
-    set_error("tile radix outside 16..512");
+    set_error("tile radix outside 16..512 (complex64: ..4096)");
     return MFFT_E_UNSUPPORTED;
 }
 
@@ -502,6 +570,7 @@ template <typename T> int tile_log2c_for(int log2g, bool narrow)
     case 7: return narrow ? TileCols<T, 7, true>::LOG2C : TileCols<T, 7, false>::LOG2C;
     case 8: return narrow ? TileCols<T, 8, true>::LOG2C : TileCols<T, 8, false>::LOG2C;
     case 9: return narrow ? TileCols<T, 9, true>::LOG2C : TileCols<T, 9, false>::LOG2C;
+    case 10: case 11: case 12: return 2;
     }
     return 0;
 }
