@@ -29,9 +29,16 @@ class Layout(ctypes.Structure):
     _fields_ = [("batch_stride", ctypes.c_int64), ("seg", ctypes.c_int64), ("seg_stride", ctypes.c_int64)]
 
 
+class PeakParams(ctypes.Structure):
+    """mfft_peak_params"""
+    _fields_ = [("dt", ctypes.c_double), ("dc_guard", ctypes.c_double), ("guard", ctypes.c_double),
+                ("include_dc", ctypes.c_int), ("mode", ctypes.c_int), ("want", ctypes.c_int)]
+
+
 SIGNATURES = {
     "mfft_version": (_int, []),
     "mfft_device_count": (_int, []),
+    "mfft_device_memory": (_int, [ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "mfft_strerror": (ctypes.c_char_p, [_int]),
     "mfft_last_error": (ctypes.c_char_p, []),
     "mfft_plan_1d": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32]),
@@ -44,6 +51,8 @@ SIGNATURES = {
     "mfft_exec": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp]),
     "mfft_exec_host": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp]),
     "mfft_lsq_normal_host": (_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _int, _vp, _vp, _vp]),
+    "mfft_lines_host": (_int, [_vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, ctypes.POINTER(PeakParams), _int, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp]),
     "mfft_lsq_normal_static": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "mfft_local_maxima": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp]),
     "mfft_exec_host_peaks": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),

@@ -81,6 +81,63 @@ __global__ void normalize_kernel(const T* in, T* out, int64_t count, const doubl
         out[i] = in[i] / den;
 }
 
+// Per-spectrum statistics {max S, sum S, sum f_k S} (f_k the signed FFT-order bin) of dense power
+// spectra, as a two-stage reduction without atomics: block (x, b) reduces its share of spectrum b
+// into partial[(b * gridDim.x + x) * 3 ..], stats_final_kernel folds the partials in a fixed order.
+// Used after multi-pass transforms, whose last pass would otherwise send three atomics per wave to
+// the same three addresses (105 us of a 150 us chirp-z execution of three 2^19-point signals).
+template <typename T>
+__global__ void __launch_bounds__(256) stats_partial_kernel(const T* S, int64_t n_out, int64_t stride, double* partial)
+{
+    __shared__ double red[4][3];
+    const int64_t b = blockIdx.y;
+    const T* s = S + b * stride;
+    double mx = 0.0, sm = 0.0, sk = 0.0;
+    const int64_t half = (n_out + 1) / 2;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_out; k += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)s[k];
+        const double f = k < half ? (double)k : (double)(k - n_out);
+        mx = v > mx ? v : mx;
+        sm += v;
+        sk += f * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double omx = __shfl_xor(mx, o, 64);
+        mx = omx > mx ? omx : mx;
+        sm += __shfl_xor(sm, o, 64);
+        sk += __shfl_xor(sk, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = mx; red[threadIdx.x >> 6][1] = sm; red[threadIdx.x >> 6][2] = sk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m2 = red[0][0], s2 = red[0][1], k2 = red[0][2];
+        for (int w = 1; w < 4; ++w) { m2 = red[w][0] > m2 ? red[w][0] : m2; s2 += red[w][1]; k2 += red[w][2]; }
+        double* out = partial + (b * gridDim.x + blockIdx.x) * 3;
+        out[0] = m2; out[1] = s2; out[2] = k2;
+    }
+}
+
+__global__ void __launch_bounds__(64) stats_final_kernel(const double* partial, int nblk, double* stats)
+{
+    const int64_t b = blockIdx.x;
+    const double* p = partial + b * nblk * 3;
+    double mx = 0.0, sm = 0.0, sk = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+        mx = p[3 * i] > mx ? p[3 * i] : mx;
+        sm += p[3 * i + 1];
+        sk += p[3 * i + 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double omx = __shfl_xor(mx, o, 64);
+        mx = omx > mx ? omx : mx;
+        sm += __shfl_xor(sm, o, 64);
+        sk += __shfl_xor(sk, o, 64);
+    }
+    if (threadIdx.x == 0) { stats[3 * b] = mx; stats[3 * b + 1] = sm; stats[3 * b + 2] = sk; }
+}
+
 // out[b][c][r] = in[b][r][c], 32x32 tiles through LDS (33-wide rows: no bank conflicts)
 template <typename T>
 __global__ void transpose_kernel(const cx<T>* in, cx<T>* out, int64_t rows, int64_t cols)
@@ -402,6 +459,171 @@ __global__ void local_maxima_kernel(const T* S, int64_t n, int64_t* idx, int64_t
             if ((int64_t)slot < capacity) idx[slot] = i;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Peak pipeline of the two estimators on the device copy of the spectra (final2.py:151-171,
+// streamlit_app_combined.py:218-228): candidates = interior local maxima (left strict, right weak),
+// plus bin 0 / minus the DC guard band in mode 0; then the guard-spaced greedy pick in order of
+// decreasing height; then the three-point log-parabola refinement of every picked line.
+// omega_k = two_pi * (f_k * inv_nd) with f_k the signed FFT-order bin and inv_nd = 1 / (n * dt):
+// the same two multiplications numpy makes, so the guard comparisons see the reference's doubles.
+// ---------------------------------------------------------------------------------------------
+struct PeakArgs {
+    int64_t n;            // bins per spectrum
+    int64_t cap;          // candidate slots per spectrum (n/2 + 2 always suffices)
+    double inv_nd;        // 1.0 / (n * dt)
+    double dc_thresh;     // mode 0 without include_dc: keep candidates with |omega| > dc_thresh
+    double guard;         // picked lines are farther apart than this (mode 1: in |omega|)
+    int include_dc;       // mode 0: bin 0 is a candidate when S[0] > 0, and no DC guard applies
+    int mode;             // 0: distance |w_k - w_j|, 1: distance ||w_k| - |w_j||, no DC handling
+    int want;             // lines to pick per spectrum, <= 64
+};
+
+__device__ __forceinline__ double peak_omega(int64_t k, int64_t n, double inv_nd)
+{
+    // two separately rounded products, as numpy evaluates them: no fused multiply-add may absorb
+    // them into a caller's subtraction (omega_k - omega_k has to be exactly zero)
+#pragma clang fp contract(off)
+    const int64_t f = k < (n + 1) / 2 ? k : k - n;
+    const double fr = (double)f * inv_nd;
+    return 6.283185307179586 * fr;
+}
+
+// cand_idx / cand_val: [batch][cap] (unordered), count: [batch] (zeroed by the caller).  A workgroup
+// scans one contiguous chunk of a spectrum, collects its candidates in LDS and reserves their
+// slots with ONE global atomic (a counter per spectrum hit once per candidate serialised the scan:
+// 138 us for three 256032-bin spectra against 6 us).
+constexpr int kPeakChunk = 2048;                 // bins per workgroup: at most 1024 local maxima + bin 0
+template <typename T>
+__global__ void __launch_bounds__(256) peak_candidates_kernel(const T* S, PeakArgs a, int64_t* cand_idx, double* cand_val,
+                                                             unsigned int* count)
+{
+    __shared__ int64_t l_idx[kPeakChunk / 2 + 2];
+    __shared__ double l_val[kPeakChunk / 2 + 2];
+    __shared__ unsigned int l_n, l_base;
+    const int64_t b = blockIdx.y;
+    const T* s = S + b * a.n;
+    for (int64_t c0 = (int64_t)blockIdx.x * kPeakChunk; c0 < a.n; c0 += (int64_t)gridDim.x * kPeakChunk) {
+        if (threadIdx.x == 0) l_n = 0;
+        __syncthreads();
+        const int64_t c1 = c0 + kPeakChunk < a.n ? c0 + kPeakChunk : a.n;
+        for (int64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
+            const T c = s[i];
+            bool take = i >= 1 && i <= a.n - 2 && c > s[i - 1] && c >= s[i + 1];
+            if (a.mode == 0) {
+                if (a.include_dc) take = take || (i == 0 && c > (T)0);
+                else take = take && fabs(peak_omega(i, a.n, a.inv_nd)) > a.dc_thresh;
+            }
+            if (take) {
+                const unsigned int slot = atomicAdd(&l_n, 1u);
+                l_idx[slot] = i;
+                l_val[slot] = (double)c;
+            }
+        }
+        __syncthreads();
+        const unsigned int found = l_n;
+        if (threadIdx.x == 0 && found > 0) l_base = atomicAdd(count + b, found);
+        __syncthreads();
+        const unsigned int base = l_base;
+        for (unsigned int k = threadIdx.x; k < found; k += blockDim.x) {
+            if ((int64_t)(base + k) < a.cap) {
+                cand_idx[b * a.cap + base + k] = l_idx[k];
+                cand_val[b * a.cap + base + k] = l_val[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per spectrum.  Round r takes the tallest remaining candidate (ties: the larger bin
+// index, as a reversed stable sort would) and strikes every candidate inside its guard band, so a
+// round compares with the newest line only.  out_idx / out_omega / out_height: [batch][want], padded
+// with -1 / 0; out_count: [batch].  cand_val is consumed (struck entries become -1).
+template <typename T>
+__global__ void __launch_bounds__(1024) peak_pick_kernel(const T* S, PeakArgs a, const int64_t* cand_idx, double* cand_val,
+                                                       const unsigned int* count, int64_t* out_idx, double* out_omega,
+                                                       double* out_height, int* out_count)
+{
+    __shared__ double red_val[16];
+    __shared__ int64_t red_idx[16];
+    __shared__ int64_t chosen[64];
+    __shared__ int n_chosen;
+    const int64_t b = blockIdx.x;
+    const T* s = S + b * a.n;
+    const int64_t* ci = cand_idx + b * a.cap;
+    double* cv = cand_val + b * a.cap;
+    const int64_t nc = (int64_t)count[b] < a.cap ? (int64_t)count[b] : a.cap;
+    if (threadIdx.x == 0) n_chosen = 0;
+    __syncthreads();
+    for (int r = 0; r < a.want; ++r) {
+        double best = -1.0;
+        int64_t best_i = -1;
+        for (int64_t j = threadIdx.x; j < nc; j += blockDim.x) {
+            const double v = cv[j];
+            const int64_t k = ci[j];
+            if (v > best || (v == best && v >= 0.0 && k > best_i)) { best = v; best_i = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64);
+            const int64_t oi = __shfl_xor(best_i, o, 64);
+            if (ov > best || (ov == best && oi > best_i)) { best = ov; best_i = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { red_val[threadIdx.x >> 6] = best; red_idx[threadIdx.x >> 6] = best_i; }
+        __syncthreads();
+        best = red_val[0]; best_i = red_idx[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (red_val[w] > best || (red_val[w] == best && red_idx[w] > best_i)) { best = red_val[w]; best_i = red_idx[w]; }
+        __syncthreads();                                   // everyone has read red_* before the next round writes
+        if (best_i < 0 || best < 0.0) break;               // uniform: no candidate left
+        if (threadIdx.x == 0) { chosen[r] = best_i; n_chosen = r + 1; }
+        const double wk = peak_omega(best_i, a.n, a.inv_nd);
+        for (int64_t j = threadIdx.x; j < nc; j += blockDim.x) {
+            if (cv[j] < 0.0) continue;
+            const double wj = peak_omega(ci[j], a.n, a.inv_nd);
+            const double d = a.mode == 0 ? fabs(wj - wk) : fabs(fabs(wj) - fabs(wk));
+            if (ci[j] == best_i || !(d > a.guard)) cv[j] = -1.0;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int got = n_chosen;
+    if (threadIdx.x == 0) out_count[b] = got;
+    if ((int)threadIdx.x < a.want) {
+        const int r = threadIdx.x;
+        int64_t i = -1;
+        double wh = 0.0, h = 0.0;
+        if (r < got) {
+            i = chosen[r];
+            const double x1 = peak_omega(i, a.n, a.inv_nd);
+            h = (double)s[i];
+            wh = x1;
+            if (i > 0 && i < a.n - 1) {                    // three-point log-parabola (final2.py:102-113)
+                const double y0 = (double)s[i - 1], y1 = h, y2 = (double)s[i + 1];
+                const double l0 = log(y0 > 1e-300 ? y0 : 1e-300), l1 = log(y1 > 1e-300 ? y1 : 1e-300),
+                             l2 = log(y2 > 1e-300 ? y2 : 1e-300);
+                const double denom = 2.0 * (l0 - 2.0 * l1 + l2);
+                if (denom != 0.0) {
+                    const double delta = (l0 - l2) / denom;
+                    const double dx = 0.5 * (peak_omega(i + 1, a.n, a.inv_nd) - peak_omega(i - 1, a.n, a.inv_nd));
+                    wh = x1 + delta * dx;
+                }
+            }
+        }
+        out_idx[b * a.want + r] = i;
+        out_omega[b * a.want + r] = wh;
+        out_height[b * a.want + r] = h;
+    }
+}
+
+// E[b][c] = -omega_hat[b][c]  (E = -omega convention of final2.py:172), zero beyond the picked lines
+__global__ void negate_lines_kernel(const double* omega_hat, const int* count, double* E, int want, int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / want, c = i - b * want;
+    E[i] = c < count[b] ? -omega_hat[i] : 0.0;
 }
 
 // out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and

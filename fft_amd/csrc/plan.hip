@@ -482,6 +482,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         MFFT_HIP(hipMalloc(&work[1], work_bytes));
         bytes += (int64_t)work_bytes;
     }
+    // statistics of dense power spectra: a reduction of their own after the last pass (no atomics)
+    const bool stats_after = io.stats && io.power && io.out_seg == 0 && work[0] != nullptr;
     const void* src = io.in;
     int64_t src_stride = io.in_stride;
     const int64_t nn = n * inner;       // elements per transform unit (one signal, or one n x inner array)
@@ -515,7 +517,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.in_seg = io.in_seg; a.in_seg_stride = io.in_seg_stride;
         }
         if (last) {
-            a.post = io.post; a.stats = io.stats; a.n_out = io.n_out;
+            a.post = io.post; a.stats = stats_after ? nullptr : io.stats; a.n_out = io.n_out;
             a.conj_out = io.conj_out; a.scale = io.scale;
             a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
         }
@@ -543,6 +545,17 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         if (rc) return rc;
         src = a.out;
         src_stride = nn;
+    }
+    if (stats_after) {
+        // the workspace is dead once the last pass has read it: it holds the per-block partials
+        int64_t nblk = (io.n_out + 4095) / 4096;
+        if (nblk > 256) nblk = 256;
+        if ((size_t)nb * (size_t)nblk * 3 * sizeof(double) > work_bytes || nb > 65535) { set_error("statistics scratch too small"); return MFFT_E_UNSUPPORTED; }
+        double* partial = static_cast<double*>(work[0]);
+        hipLaunchKernelGGL(stats_partial_kernel<T>, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, s,
+                           static_cast<const T*>(io.out), io.n_out, io.out_stride, partial);
+        hipLaunchKernelGGL(stats_final_kernel, dim3((unsigned)nb), dim3(64), 0, s, (const double*)partial, (int)nblk, io.stats);
+        MFFT_HIP(hipGetLastError());
     }
     return MFFT_OK;
 }
@@ -576,6 +589,9 @@ struct Plan {
     hipStream_t s_run = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int64_t pipe_slab = 0;        // signals per slab
+    char* d_lines = nullptr;      // candidate lists, picked lines, line positions, Gram blocks, time grid (mfft_lines_host)
+    char* h_lines = nullptr;      // pinned mirror of the small results in d_lines
+    int lines_want = 0;
     int64_t* d_peaks = nullptr;   // {max, sum, centroid} | count | candidate indices (mfft_exec_host_peaks)
     int64_t* h_peaks = nullptr;   // pinned mirror of d_peaks
     int64_t peak_cap = 0;
@@ -604,9 +620,9 @@ static void plan_free(Plan* p)
     (void)hipSetDevice(p->device);
     p->eng.release();
     for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
-                    (void*)p->d_peaks})
+                    (void*)p->d_peaks, (void*)p->d_lines})
         if (q) (void)hipFree(q);
-    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks})
+    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines})
         if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1]})
         if (e) (void)hipEventDestroy(e);
@@ -935,6 +951,17 @@ int mfft_device_count(void)
         return MFFT_E_NODEVICE;
     }
     return n;
+}
+
+int mfft_device_memory(int64_t* free_bytes, int64_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) { set_error("null argument"); return MFFT_E_INVALID; }
+    if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
+    size_t f = 0, t = 0;
+    MFFT_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return MFFT_OK;
 }
 
 const char* mfft_strerror(int code)
@@ -1343,6 +1370,147 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
         MFFT_HIP(hipMemcpy(p->h_peaks + kHead + first, p->d_peaks + kHead + first, sizeof(int64_t) * (size_t)(take - first),
                            hipMemcpyDeviceToHost));
     if (take > 0) memcpy(h_idx, p->h_peaks + kHead, sizeof(int64_t) * (size_t)take);
+    return MFFT_OK;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, double t0, double dt,
+                    const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
+                    int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram)
+{
+    if (!plan || !h_x || !prm || !h_idx || !h_omega_hat || !h_count || !h_stats) { set_error("null argument"); return MFFT_E_INVALID; }
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    const uint32_t need = MFFT_POWER | MFFT_STATS;
+    if ((p->flags & need) != need || p->kind == Plan::COLUMNS) { set_error("the line search needs an MFFT_POWER | MFFT_STATS plan"); return MFFT_E_INVALID; }
+    if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg) { set_error("host entry points serve dense layouts only"); return MFFT_E_UNSUPPORTED; }
+    if (prm->want < 1 || prm->want > 64) { set_error("1 <= want <= 64 lines"); return MFFT_E_INVALID; }
+    if (prm->mode != 0 && prm->mode != 1) { set_error("peak mode must be 0 or 1"); return MFFT_E_INVALID; }
+    if (!(prm->dt > 0.0) || !(prm->guard >= 0.0)) { set_error("bad peak parameters"); return MFFT_E_INVALID; }
+    if (h_gram) {
+        if (!h_times) { set_error("the line fit needs the time grid"); return MFFT_E_INVALID; }
+        if (p->dtype != MFFT_C128 || (p->flags & (MFFT_REAL_IN | MFFT_DEMOD))) {
+            set_error("the fused line fit takes complex128 samples without demodulation");
+            return MFFT_E_UNSUPPORTED;
+        }
+    }
+    if (p->batch > 65535) { set_error("at most 65535 spectra per call"); return MFFT_E_UNSUPPORTED; }
+    DeviceGuard g(p->device);
+    if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
+    std::lock_guard<std::mutex> lock(p->mu);
+    const size_t rs = real_size(p->dtype);
+    const int64_t B = p->batch, n = p->n, n_in = p->n_in;
+    const int want = prm->want;
+    const size_t in_bytes = (size_t)B * (size_t)n_in * rs * ((p->flags & MFFT_REAL_IN) ? 1 : 2);
+    const size_t out_bytes = (size_t)B * (size_t)n * rs;
+    if (!p->d_out) MFFT_HIP(hipMalloc(&p->d_out, out_bytes));
+    // One device block and its pinned mirror, so that a call is one upload, one download of the small
+    // results and one download of the spectra:
+    //   up:    samples | time grid
+    //   work:  candidate lists | candidate counts | line positions E
+    //   down:  statistics | picked bins | omega_hat | heights | lines found | Gram blocks
+    const int64_t cap = n / 2 + 2;
+    const size_t nres = 2 * (size_t)want * want + 2 * (size_t)want + 1;
+    const size_t o_x = 0, o_t = align256(o_x + in_bytes), up_bytes = o_t + sizeof(double) * (size_t)n_in;
+    const size_t o_cidx = align256(up_bytes), o_cval = align256(o_cidx + sizeof(int64_t) * (size_t)(B * cap));
+    const size_t o_count = align256(o_cval + sizeof(double) * (size_t)(B * cap));
+    const size_t o_E = align256(o_count + sizeof(unsigned int) * (size_t)B);
+    const size_t o_down = align256(o_E + sizeof(double) * (size_t)(B * want));
+    const size_t o_stats = o_down, o_idx = o_stats + sizeof(double) * 3 * (size_t)B;
+    const size_t o_om = o_idx + sizeof(int64_t) * (size_t)(B * want), o_h = o_om + sizeof(double) * (size_t)(B * want);
+    const size_t o_n = o_h + sizeof(double) * (size_t)(B * want);
+    const size_t o_gram = (o_n + sizeof(int) * (size_t)B + 7) & ~size_t(7);
+    const size_t total = o_gram + sizeof(double) * (size_t)B * nres;
+    const size_t down_bytes = total - o_down;
+    if (!p->d_lines || p->lines_want != want) {
+        if (p->d_lines) (void)hipFree(p->d_lines);
+        if (p->h_lines) (void)hipHostFree(p->h_lines);
+        p->d_lines = nullptr; p->h_lines = nullptr; p->lines_want = 0;
+        MFFT_HIP(hipMalloc((void**)&p->d_lines, total));
+        MFFT_HIP(hipHostMalloc((void**)&p->h_lines, up_bytes + down_bytes, hipHostMallocDefault));
+        p->lines_want = want;
+    }
+    char* d = p->d_lines;
+    char* h_up = p->h_lines;
+    char* h_down = p->h_lines + up_bytes;
+    int64_t* d_cidx = reinterpret_cast<int64_t*>(d + o_cidx);
+    double* d_cval = reinterpret_cast<double*>(d + o_cval);
+    unsigned int* d_cnt = reinterpret_cast<unsigned int*>(d + o_count);
+    double* d_stats = reinterpret_cast<double*>(d + o_stats);
+    int64_t* d_idx = reinterpret_cast<int64_t*>(d + o_idx);
+    double* d_om = reinterpret_cast<double*>(d + o_om);
+    double* d_h = reinterpret_cast<double*>(d + o_h);
+    int* d_n = reinterpret_cast<int*>(d + o_n);
+    double* d_gram = reinterpret_cast<double*>(d + o_gram);
+    double* d_E = reinterpret_cast<double*>(d + o_E);
+    const double* d_t = reinterpret_cast<const double*>(d + o_t);
+
+    memcpy(h_up + o_x, h_x, in_bytes);
+    if (h_gram) memcpy(h_up + o_t, h_times, sizeof(double) * (size_t)n_in);
+    MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, nullptr));
+    int rc = plan_exec(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, nullptr);
+    if (rc) return rc;
+    PeakArgs a;
+    a.n = n; a.cap = cap;
+    a.inv_nd = 1.0 / ((double)n * prm->dt);
+    a.dc_thresh = prm->dc_guard; a.guard = prm->guard;
+    a.include_dc = prm->include_dc; a.mode = prm->mode; a.want = want;
+    MFFT_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)B, nullptr));
+    int64_t blocks = (n + kPeakChunk - 1) / kPeakChunk;
+    if (blocks > 1024) blocks = 1024;
+    const int pick_threads = n >= 16384 ? 1024 : 256;
+    if (p->dtype == MFFT_C64) {
+        hipLaunchKernelGGL(peak_candidates_kernel<float>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
+                           static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt);
+        hipLaunchKernelGGL(peak_pick_kernel<float>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
+                           static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n);
+    } else {
+        hipLaunchKernelGGL(peak_candidates_kernel<double>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
+                           static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt);
+        hipLaunchKernelGGL(peak_pick_kernel<double>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
+                           static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n);
+    }
+    MFFT_HIP(hipGetLastError());
+    if (h_gram) {
+        const int tot = (int)(B * want);
+        hipLaunchKernelGGL(negate_lines_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, d_om, d_n, d_E, want, tot);
+        MFFT_HIP(hipGetLastError());
+        // sub-batches sized to the fixed scratch of the reduction
+        const int nchunk = (want + kLsqCols - 1) / kLsqCols;
+        int64_t per = (int64_t)(kScratchDoubles / ((size_t)want * nchunk * kLsqSlot));
+        if (per > 65535 / nchunk) per = 65535 / nchunk;
+        if (per < 1) { set_error("line fit does not fit the reduction scratch"); return MFFT_E_UNSUPPORTED; }
+        // the reduction's scratch is one array per GPU: keep other threads' launches out of the
+        // partial -> final pairs (all of them go to the null stream, so launch order is execution order)
+        static std::mutex scratch_mu;
+        std::lock_guard<std::mutex> scratch_lock(scratch_mu);
+        for (int64_t b0 = 0; b0 < B; b0 += per) {
+            const int64_t nb = B - b0 < per ? B - b0 : per;
+            rc = mfft_lsq_normal_static(reinterpret_cast<const cx<double>*>(d + o_x) + b0 * n_in,
+                                        (p->flags & MFFT_HANN) ? static_cast<const double*>(p->d_win) : nullptr, d_t, n_in,
+                                        nb, nullptr, d_E + b0 * want, want, d_gram + (size_t)b0 * nres, nullptr);
+            if (rc) return rc;
+        }
+    }
+    MFFT_HIP(hipMemcpyAsync(h_down, d + o_down, h_gram ? down_bytes : (o_gram - o_down), hipMemcpyDeviceToHost, nullptr));
+    if (h_S) {
+        if (normalize) {
+            // S / (S.max() if S.max() > 0 else 1.0), per spectrum, in place on the device copy (final2.py:146)
+            for (int64_t b = 0; b < B; ++b) {
+                rc = mfft_normalize_by_max(static_cast<char*>(p->d_out) + (size_t)b * n * rs,
+                                           static_cast<char*>(p->d_out) + (size_t)b * n * rs, n, d_stats + 3 * b, p->dtype, nullptr);
+                if (rc) return rc;
+            }
+        }
+        MFFT_HIP(hipMemcpyAsync(h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, nullptr));
+    }
+    MFFT_HIP(hipStreamSynchronize(nullptr));
+    memcpy(h_stats, h_down + (o_stats - o_down), sizeof(double) * 3 * (size_t)B);
+    memcpy(h_idx, h_down + (o_idx - o_down), sizeof(int64_t) * (size_t)(B * want));
+    memcpy(h_omega_hat, h_down + (o_om - o_down), sizeof(double) * (size_t)(B * want));
+    if (h_height) memcpy(h_height, h_down + (o_h - o_down), sizeof(double) * (size_t)(B * want));
+    memcpy(h_count, h_down + (o_n - o_down), sizeof(int) * (size_t)B);
+    if (h_gram) memcpy(h_gram, h_down + (o_gram - o_down), sizeof(double) * (size_t)B * nres);
     return MFFT_OK;
 }
 

@@ -132,6 +132,43 @@ class Plan:
             return out, stats, int(count.value)
         return out, stats, np.sort(idx[:count.value])
 
+    def exec_host_lines(self, x: np.ndarray, times=None, *, axis_dt: float, guard: float, want: int,
+                        dc_guard: float = 0.0, include_dc: bool = False, mode: int = 0, scale: float = 1.0,
+                        mu: float = 0.0, t0: float = 0.0, dt: float = 1.0, want_spectrum: bool = True,
+                        want_fit: bool = False, normalize: bool = False):
+        """Spectra, statistics and the picked / refined spectral lines of every signal of the batch in
+        one call (mfft_lines_host).  Returns a dict: S (batch, n) or None (each spectrum divided by its
+        guarded maximum on the device when `normalize`), stats (batch, 3) of the unnormalised spectra, idx /
+        omega_hat / height (batch, want), count (batch,), gram (batch, 2*want*want + 2*want + 1) or
+        None.  `times` (n_in doubles) is needed for the fit only."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        x = np.ascontiguousarray(x, dtype=self.in_dtype)
+        if x.size != self.batch * self.n_in:
+            raise ValueError(f"input has {x.size} elements, plan expects {self.batch}x{self.n_in}")
+        want = int(want)
+        prm = _lib.PeakParams(float(axis_dt), float(dc_guard), float(guard), int(bool(include_dc)), int(mode), want)
+        B = self.batch
+        S = np.empty((B, self.n), dtype=self.out_dtype) if want_spectrum else None
+        stats = np.zeros((B, 3), dtype=np.float64)
+        idx = np.empty((B, max(want, 1)), dtype=np.int64)
+        om = np.empty((B, max(want, 1)), dtype=np.float64)
+        hgt = np.empty((B, max(want, 1)), dtype=np.float64)
+        cnt = np.zeros(B, dtype=np.int32)
+        gram = np.empty((B, 2 * want * want + 2 * want + 1), dtype=np.float64) if want_fit else None
+        t = None
+        if want_fit:
+            t = np.ascontiguousarray(times, dtype=np.float64)
+            if t.shape[0] != self.n_in:
+                raise ValueError("`times` must have one entry per sample")
+        with self._lock:
+            _lib.check(_lib.load().mfft_lines_host(
+                self._h, x.ctypes.data, float(scale), float(mu), float(t0), float(dt),
+                t.ctypes.data if t is not None else None, ctypes.byref(prm), int(bool(normalize)),
+                S.ctypes.data if S is not None else None, stats.ctypes.data, idx.ctypes.data, om.ctypes.data,
+                hgt.ctypes.data, cnt.ctypes.data, gram.ctypes.data if gram is not None else None))
+        return {"S": S, "stats": stats, "idx": idx, "omega_hat": om, "height": hgt, "count": cnt, "gram": gram}
+
     # -- lifetime ---------------------------------------------------------------
     def destroy(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -8,6 +8,9 @@ arrays; the transform itself always runs on the GPU (no host fallback).
 """
 from __future__ import annotations
 
+import ctypes
+import gc
+import os
 import threading
 from collections import OrderedDict
 
@@ -18,7 +21,63 @@ from .engine import ColumnPlan, Plan
 
 _CACHE_MAX = 24
 _cache: "OrderedDict[tuple, Plan]" = OrderedDict()
+_cache_bytes: "dict[tuple, int]" = {}
 _cache_lock = threading.Lock()
+_budget = None
+
+
+def _cache_budget() -> int:
+    """Device bytes the cached plans may hold together: MFFT_CACHE_BYTES, else half of the device's
+    memory (a chirp-z plan at the apps' largest length holds ~18 GiB, so a count alone does not
+    bound the cache)."""
+    global _budget
+    if _budget is None:
+        env = os.environ.get("MFFT_CACHE_BYTES")
+        if env:
+            _budget = int(env)
+        else:
+            free, total = ctypes.c_int64(), ctypes.c_int64()
+            rc = _lib.load().mfft_device_memory(ctypes.byref(free), ctypes.byref(total))
+            _budget = total.value // 2 if rc == _lib.OK else 1 << 62
+    return _budget
+
+
+def _held_bytes(plan) -> int:
+    """Device memory a plan holds or will hold: tables and workspace plus the staging buffers its
+    host entry points allocate on first use (input, output)."""
+    if plan is None:
+        return 0
+    csz = 8 if plan.dtype == _lib.C64 else 16
+    inner = getattr(plan, "inner", 1)
+    in_sz = csz // 2 if plan.flags & _lib.REAL_IN else csz
+    out_sz = csz // 2 if plan.flags & _lib.POWER else csz
+    return plan.workspace_bytes + plan.batch * inner * (plan.n_in * in_sz + plan.n * out_sz)
+
+
+def _build(factory):
+    """Build a plan; if the device is out of memory, drop every cached plan (each frees its memory
+    when its last user lets go) and try once more."""
+    try:
+        return factory()
+    except _lib.MfftError as exc:
+        if "out of memory" not in str(exc):
+            raise
+    clear_plan_cache()
+    gc.collect()
+    return factory()
+
+
+def _insert(key, plan):
+    """Cache lock held.  Adds the plan, then drops least recently used entries while the cache
+    exceeds its entry count or its byte budget (the newest entry always stays).  A dropped plan is
+    not destroyed here: another thread may be executing it; it frees its device memory when the
+    last reference goes (Plan.__del__)."""
+    _cache[key] = plan
+    _cache_bytes[key] = _held_bytes(plan)
+    budget = _cache_budget()
+    while len(_cache) > 1 and (len(_cache) > _CACHE_MAX or sum(_cache_bytes.values()) > budget):
+        old, _ = _cache.popitem(last=False)
+        _cache_bytes.pop(old, None)
 
 
 def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int, device=None) -> Plan:
@@ -32,23 +91,14 @@ def cached_plan(n: int, n_in: int, batch: int, dtype: int, flags: int, device=No
         if plan is not None:
             _cache.move_to_end(key)
             return plan
-    plan = Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags)
+    plan = _build(lambda: Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags))
     with _cache_lock:
         other = _cache.get(key)
         if other is not None:          # another thread built the same plan meanwhile
             plan.destroy()
             return other
-        _cache[key] = plan
-        _evict()
+        _insert(key, plan)
     return plan
-
-
-def _evict():
-    """Drop the least recently used plans (cache lock held).  A dropped plan is not destroyed
-    here: another thread may be executing it; it frees its device memory when the last reference
-    goes (Plan.__del__)."""
-    while len(_cache) > _CACHE_MAX:
-        _cache.popitem(last=False)
 
 
 def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
@@ -60,8 +110,10 @@ def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
             _cache.move_to_end(key)
             return _cache[key]
     try:
-        plan = ColumnPlan(n, inner, batch=batch, dtype=dtype)
-    except _lib.MfftError:
+        plan = _build(lambda: ColumnPlan(n, inner, batch=batch, dtype=dtype))
+    except _lib.MfftError as exc:
+        if "out of memory" in str(exc):
+            raise
         plan = None
     with _cache_lock:
         other = _cache.get(key)
@@ -69,8 +121,7 @@ def cached_column_plan(n: int, inner: int, batch: int, dtype: int, device=None):
             if plan is not None:
                 plan.destroy()
             return other
-        _cache[key] = plan
-        _evict()
+        _insert(key, plan)
     return plan
 
 
@@ -92,6 +143,7 @@ def clear_plan_cache():
     """Forget every cached plan; each frees its device memory once no caller holds it any more."""
     with _cache_lock:
         _cache.clear()
+        _cache_bytes.clear()
 
 
 def engine_dtype(a: np.ndarray):

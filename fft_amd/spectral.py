@@ -6,15 +6,17 @@
 
 What runs where.  The window, zero padding, demodulation, forward transform,
 ``dt`` scaling, power spectrum and the max / centroid reductions run on the GPU
-as one fused plan (final2.py:139-146, streamlit_app_combined.py:199-215); the
-float64 power spectrum comes back once, together with the indices of its local
-maxima (scanned on the device).  The tall reductions of the tail also run on the
-GPU: the return-amplitude generator f(t) (final2.py:85-97) and the normal
-equations of the windowed least squares, including all 2^k fits of the sign
-search (final2.py:174-175, streamlit_app_combined.py:233-246).  What stays on the
-host is O(#peaks) scalar work: ranking the candidates, the guard-spaced pick, the
-log-parabolic refinement, k x k solves, and the eigendecomposition of the L <= 10
-block.
+as one fused plan (final2.py:139-146, streamlit_app_combined.py:199-215).  So does
+the peak pipeline on the device copy of the spectrum -- local-maximum scan, DC
+guard, ranking by height, guard-spaced greedy pick and log-parabolic refinement
+(final2.py:151-171, streamlit_app_combined.py:218-228) -- and the tall reductions
+of the tail: the return-amplitude generator f(t) (final2.py:85-97) and the normal
+equations of the windowed least squares, including all 2^k fits of the sign search
+(final2.py:174-175, streamlit_app_combined.py:233-246).  ``fft_from_timeseries_batch``
+does all of that for several signals (the app's blocks m) in one device pass.  What
+stays on the host is O(#lines) scalar work: k x k solves, pruning, sorting, and the
+eigendecomposition of the L <= 10 block.  The float64 spectrum comes back once
+because both functions return it.
 
 There is no CPU fallback for the transform: without libmfft.so or without a GPU
 these functions raise.
@@ -93,20 +95,6 @@ def power_spectrum(x, nfft: int, dt: float, use_hann: bool = True, mu: float = 0
 
 # --------------------------------------------------------------------------- host tail
 
-def _refine_log_parabola(x, y, i):
-    """Vertex of the parabola through (x, log y) at i-1, i, i+1; x[i] at the edges or
-    when the three points are collinear."""
-    if i <= 0 or i >= len(y) - 1:
-        return x[i]
-    l0 = np.log(max(y[i - 1], 1e-300))
-    l1 = np.log(max(y[i], 1e-300))
-    l2 = np.log(max(y[i + 1], 1e-300))
-    curv = 2.0 * (l0 - 2.0 * l1 + l2)
-    if curv == 0:
-        return x[i]
-    return x[i] + ((l0 - l2) / curv) * (0.5 * (x[i + 1] - x[i - 1]))
-
-
 _hann_cache: "OrderedDict[int, np.ndarray]" = OrderedDict()
 
 
@@ -128,23 +116,6 @@ def _hanning(m: int) -> np.ndarray:
 
 def _window_of(f_t, use_hann):
     return _hanning(len(f_t)) if use_hann else np.ones_like(f_t)
-
-
-def _by_height(cand, heights, first=64):
-    """Candidates in order of decreasing height (np.argsort(...)[::-1], final2.py:161,
-    streamlit_app_combined.py:222), sorting only the tallest `first` unless the caller walks past
-    them: the guard-spaced pick usually stops within the first few."""
-    if cand.size <= 4 * first:
-        yield from cand[np.argsort(heights)[::-1]]
-        return
-    top = np.argpartition(heights, -first)[-first:]
-    top = top[np.argsort(heights[top])[::-1]]
-    yield from cand[top]
-    seen = np.zeros(cand.size, bool)
-    seen[top] = True
-    for i in np.argsort(heights)[::-1]:
-        if not seen[i]:
-            yield cand[i]
 
 
 def _normal_equations(x, win, times, E_cols, mu=0.0):
@@ -211,6 +182,83 @@ def _sign_search(G, r, yy, k, chunk=4096):
 
 # --------------------------------------------------------------------------- estimator A
 
+def fft_from_timeseries_batch(
+    f_ts,
+    times,
+    n_levels=3,
+    pad_factor=16,
+    use_hann=True,
+    include_dc=False,
+    dc_guard=1.5,
+    post_prune=True,
+    min_weight=1e-6,
+    keep_top=None,
+    guard_mult=1.2,
+):
+    """``fft_from_timeseries`` for several signals on one time grid -- the app's loop over the
+    blocks m (final2.py:752-758) as ONE device pass: one upload, one batched plan, the peak
+    pipeline and the normal equations of every signal on the device, one download.
+
+    ``f_ts``: sequence of equally long signals, or an array of shape (B, N0).  Returns a list of
+    B tuples ``(E_hat ascending, p, -omega, S_norm)``, each what the single-signal function
+    returns for that signal."""
+    times = np.asarray(times, float)
+    f_ts = [np.asarray(f) for f in f_ts]
+    if times.ndim != 1 or times.size < 2:
+        raise ValueError("`times` must be 1D with length >= 2.")
+    for f in f_ts:
+        if f.ndim < 1 or f.shape[0] != times.shape[0]:
+            raise ValueError("`f_t` and `times` must have the same length.")
+    steps = np.diff(times)
+    if not np.allclose(steps, steps[0]):
+        raise ValueError("`times` must be uniformly spaced.")
+    dt = float(steps[0])
+    if not f_ts:
+        return []
+    n0 = times.shape[0]
+    nfft = int(max(1, pad_factor) * n0)
+    want = max(n_levels, 1)
+    if want > 64:
+        raise ValueError("at most 64 spectral lines can be fitted at once")
+    B = len(f_ts)
+    x = np.empty((B, n0), dtype=np.complex128)
+    for b, f in enumerate(f_ts):
+        x[b] = f
+
+    span = times[-1] - times[0]
+    domega = TWO_PI / (span + 1e-12)
+    flags = _lib.POWER | _lib.STATS | (_lib.HANN if use_hann else 0)
+    plan = cached_plan(nfft, n0, B, _lib.C128, flags)
+    res = plan.exec_host_lines(x, times, axis_dt=dt, guard=guard_mult * domega, want=want,
+                               dc_guard=dc_guard * domega, include_dc=bool(include_dc), mode=0, scale=dt,
+                               want_spectrum=True, want_fit=True, normalize=True)
+    omega = _omega_axis(nfft, dt)
+    out = []
+    for b in range(B):
+        S_norm = res["S"][b]                       # divided by its guarded maximum on the device
+        E_axis = -omega                            # a fresh array per signal, as the reference returns
+        k = int(res["count"][b])
+        if k == 0:
+            out.append((np.array([]), np.array([]), E_axis, S_norm))
+            continue
+        E_hat = -res["omega_hat"][b, :k]
+        g = res["gram"][b]
+        G = g[:2 * want * want].view(np.complex128).reshape(want, want)
+        r = g[2 * want * want:2 * want * want + 2 * want].view(np.complex128)
+        _, p, _ = _solve_normal(G, r, float(g[-1]), np.arange(k))
+        if post_prune:
+            keep = p > min_weight
+            E_hat, p = E_hat[keep], p[keep]
+            if keep_top is not None and E_hat.size > keep_top:
+                top = np.argsort(p)[::-1][:keep_top]
+                E_hat, p = E_hat[top], p[top]
+            if p.sum() > 0:
+                p = p / p.sum()
+        order = np.argsort(E_hat)
+        out.append((E_hat[order], p[order], E_axis, S_norm))
+    return out
+
+
 def fft_from_timeseries(
     f_t,
     times,
@@ -234,51 +282,9 @@ def fft_from_timeseries(
         raise ValueError("`times` must be 1D with length >= 2.")
     if f_t.shape[0] != times.shape[0]:
         raise ValueError("`f_t` and `times` must have the same length.")
-    steps = np.diff(times)
-    if not np.allclose(steps, steps[0]):
-        raise ValueError("`times` must be uniformly spaced.")
-    dt = float(steps[0])
-
-    n0 = len(f_t)
-    nfft = int(max(1, pad_factor) * n0)
-    S, smax, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), want_peaks=True)
-    omega = _omega_axis(nfft, dt)
-    S_norm = S / (smax if smax > 0 else 1.0)
-
-    span = times[-1] - times[0]
-    domega = TWO_PI / (span + 1e-12)
-    if include_dc:
-        if S[0] > 0:
-            cand = np.concatenate(([0], cand))          # interior maxima start at 1: still ascending and unique
-    else:
-        cand = cand[np.abs(omega[cand]) > dc_guard * domega]
-    if cand.size == 0:
-        return np.array([]), np.array([]), -omega, S_norm
-
-    guard = guard_mult * domega
-    want = max(n_levels, 1)
-    chosen = []
-    for k in _by_height(cand, S[cand]):
-        if all(abs(omega[k] - omega[j]) > guard for j in chosen):
-            chosen.append(int(k))
-        if len(chosen) >= want:
-            break
-    E_hat = -np.array([_refine_log_parabola(omega, S, i) for i in chosen])
-
-    if E_hat.size > 64:
-        raise ValueError("at most 64 spectral lines can be fitted at once")
-    G, r, yy = _normal_equations(f_t, _hanning(n0) if use_hann else None, times, E_hat)
-    _, p, _ = _solve_normal(G, r, yy, np.arange(E_hat.size))
-    if post_prune:
-        keep = p > min_weight
-        E_hat, p = E_hat[keep], p[keep]
-        if keep_top is not None and E_hat.size > keep_top:
-            top = np.argsort(p)[::-1][:keep_top]
-            E_hat, p = E_hat[top], p[top]
-        if p.sum() > 0:
-            p = p / p.sum()
-    order = np.argsort(E_hat)
-    return E_hat[order], p[order], -omega, S_norm
+    return fft_from_timeseries_batch([f_t], times, n_levels=n_levels, pad_factor=pad_factor, use_hann=use_hann,
+                                     include_dc=include_dc, dc_guard=dc_guard, post_prune=post_prune,
+                                     min_weight=min_weight, keep_top=keep_top, guard_mult=guard_mult)[0]
 
 
 # --------------------------------------------------------------------------- estimator B
@@ -356,20 +362,18 @@ def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=T
                                                    want_spectrum=False)
         if ssum > 0:
             mu = float((TWO_PI / (nfft * dt)) * centroid_bins / ssum)
-    S, _, _, _, cand = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann), mu=mu if demod else 0.0,
-                                      t0=float(times[0]), want_peaks=True)
     omega = _omega_axis(nfft, dt).copy()
-    if cand.size == 0:
-        return np.array([]), np.array([]), omega, S, mu
+    # main pass: demodulated spectrum plus, on its device copy, the local maxima ranked by height and
+    # de-duplicated on |omega| (the first n_peaks the reference's loop keeps are the first n_peaks it
+    # picks: it walks the candidates by decreasing height)
     tol = TWO_PI / (times[-1] - times[0] + 1e-12)
-    limit = max(n_peaks * 3, n_peaks)
-    chosen = []
-    for k in _by_height(cand, S[cand]):
-        if len(chosen) >= limit:
-            break
-        if all(abs(abs(omega[k]) - abs(omega[j])) > 0.6 * tol for j in chosen):
-            chosen.append(int(k))
-    chosen = sorted(chosen, key=lambda j: S[j], reverse=True)[:n_peaks]
+    shift = mu if (demod and mu != 0.0) else 0.0
+    flags = _lib.POWER | _lib.STATS | (_lib.HANN if use_hann else 0) | (_lib.DEMOD if shift != 0.0 else 0)
+    plan = cached_plan(nfft, n0, 1, _lib.C128, flags)
+    res = plan.exec_host_lines(np.ascontiguousarray(f_t, dtype=np.complex128), axis_dt=dt, guard=0.6 * tol,
+                               want=max(int(n_peaks), 1), mode=1, scale=dt, mu=shift, t0=float(times[0]), dt=dt)
+    S = res["S"][0]
+    chosen = [int(i) for i in res["idx"][0, :int(res["count"][0])]][:max(int(n_peaks), 0)]
     if len(chosen) == 0:
         return np.array([]), np.array([]), omega, S, mu
     mags = np.sort(np.unique(np.round(np.abs(omega[chosen]), 12)))[:n_peaks]

@@ -53,6 +53,7 @@ typedef struct mfft_plan_s* mfft_plan;
 
 int         mfft_version(void);            /* 10000*major + 100*minor + patch */
 int         mfft_device_count(void);       /* number of HIP devices, or MFFT_E_NODEVICE */
+int         mfft_device_memory(int64_t* free_bytes, int64_t* total_bytes);   /* of the current device (plan caches size themselves by it) */
 const char* mfft_strerror(int code);
 const char* mfft_last_error(void);
 
@@ -148,6 +149,39 @@ int mfft_local_maxima(const void* d_S, int64_t n, int dtype, int64_t* d_idx, int
 int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu,
                          double t0, double dt, double* h_stats, int64_t* h_idx, int64_t capacity,
                          int64_t* h_count);
+
+/* ---- spectral lines of a batch of signals, one call ------------------------------------
+ * What both estimators do between the power spectrum and the k x k solve, for every signal of
+ * the plan's batch, on the device copy of the spectra:
+ *   candidates   interior local maxima of S (rule above); mode 0 adds bin 0 when include_dc and
+ *                S[0] > 0, otherwise drops |omega| <= dc_guard                       final2.py:151-156
+ *   pick         walk the candidates by decreasing S, keep one when it is farther than `guard`
+ *                from every line kept so far, stop at `want` lines                   final2.py:161-169
+ *                (mode 1 measures the distance between |omega| values:  streamlit_app_combined.py:221-227)
+ *   refine       three-point log-parabola around each kept bin                       final2.py:102-113, :171
+ *   fit          (h_gram != NULL, mode 0) normal equations of the windowed least squares with
+ *                columns E = -omega_hat, laid out per signal as mfft_lsq_normal_host  final2.py:174-175
+ * omega_k = 2*pi * (f_k * (1 / (n*dt))), f_k the signed FFT-order bin: numpy's own doubles.  Equal
+ * heights are taken in order of decreasing bin index.
+ * plan: MFFT_POWER | MFFT_STATS (complex128 without MFFT_REAL_IN / MFFT_DEMOD when h_gram is asked
+ * for).  h_x: batch*n_in samples; scale, mu, t0, dt as mfft_exec_host; h_times: n_in doubles (fit
+ * only).  Outputs: h_S batch*n reals (may be NULL; with `normalize` each spectrum is divided on the
+ * device by its maximum, or by 1 when that is not positive: final2.py:146), h_stats 3*batch (of the
+ * unnormalised spectra), h_idx / h_omega_hat / h_height
+ * batch*want in pick order (idx -1 beyond h_count[b]; h_height may be NULL), h_gram batch *
+ * (2*want*want + 2*want + 1) doubles (columns beyond h_count[b] carry E = 0 and are to be ignored).
+ * Synchronous; one upload and one download per array. */
+typedef struct mfft_peak_params {
+    double dt;          /* sample spacing of the time series (sets the omega axis) */
+    double dc_guard;    /* mode 0, include_dc == 0: candidates need |omega| > dc_guard */
+    double guard;       /* minimum spacing of kept lines */
+    int include_dc;
+    int mode;           /* 0 = final2.py, 1 = streamlit_app_combined.py */
+    int want;           /* lines to keep per signal, 1..64 */
+} mfft_peak_params;
+int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, double t0, double dt,
+                    const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
+                    int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram);
 
 /* ---- weights of the spectral lines ----------------------------------------------
  * Normal equations of the windowed least-squares fit both estimators end with

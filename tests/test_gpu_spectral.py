@@ -351,3 +351,153 @@ def test_plan_cache_eviction_while_in_use(fa, monkeypatch):
     [t.join() for t in threads]
     npfft.clear_plan_cache()
     assert not errors, errors
+
+
+def test_plan_cache_is_bounded_by_device_bytes(fa, monkeypatch):
+    """The cache evicts by the device memory its plans hold, not only by their number: cycling
+    through more large lengths than the count limit never holds more than the byte budget (plus
+    the newest plan), every transform stays correct, and an out-of-memory build clears the cache
+    and retries."""
+    import ctypes
+    from fft_amd import npfft, _lib
+    npfft.clear_plan_cache()
+    monkeypatch.setattr(npfft, "_budget", 192 << 20)               # 192 MiB
+    free0, total = ctypes.c_int64(), ctypes.c_int64()
+    lib = _lib.load()
+    lib.mfft_device_memory(ctypes.byref(free0), ctypes.byref(total))
+    assert 0 < free0.value <= total.value
+    rng = np.random.default_rng(12)
+    lengths = [1_000_003 + 1009 * i for i in range(30)]             # chirp-z plans of ~100 MiB each
+    for n in lengths:
+        x = rng.standard_normal(2000) + 1j * rng.standard_normal(2000)
+        y = fa.fft(x, n=n)
+        k = np.array([0, 1, n // 3, n - 1])
+        want = (x[None, :] * np.exp(-2j * np.pi * ((k[:, None] * np.arange(2000)[None, :]) % n) / n)).sum(axis=1)
+        assert np.max(np.abs(y[k] - want)) < 1e-10
+        with npfft._cache_lock:
+            held = sum(npfft._cache_bytes.values())
+            newest = npfft._cache_bytes[next(reversed(npfft._cache))]
+            assert held - newest <= (192 << 20) and len(npfft._cache) <= npfft._CACHE_MAX
+    import gc
+    gc.collect()
+    free1 = ctypes.c_int64()
+    lib.mfft_device_memory(ctypes.byref(free1), ctypes.byref(total))
+    assert free0.value - free1.value < (1 << 30), "evicted plans must release their device memory"
+    # an allocation failure drops the cache and retries once
+    calls = {"n": 0}
+
+    def flaky():
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise _lib.MfftError("out of memory: hipMalloc failed")
+        return "built"
+    assert npfft._build(flaky) == "built" and calls["n"] == 2 and len(npfft._cache) == 0
+    npfft.clear_plan_cache()
+
+
+def test_batched_estimator_reproduces_goldens_in_one_call(fa, golden):
+    """The app's loop over blocks m = 0, 1, 2 (final2.py:752-758) as one batched call: every
+    block's (E, p, axis, S_norm) equals the reference's own output (golden) and what the
+    single-signal function returns."""
+    z = golden("final2_defaults.npz")
+    times = np.arange(0.0, float(z["tmax"]) + float(z["dt"]), float(z["dt"]))
+    kw = dict(n_levels=3, pad_factor=32, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=3)
+    res = fa.fft_from_timeseries_batch([z[f"f_t_{m}"] for m in (0, 1, 2)], times, **kw)
+    assert len(res) == 3
+    for m, (E, p, Eaxis, S_norm) in enumerate(res):
+        np.testing.assert_allclose(E, z[f"E_{m}"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p, z[f"p_{m}"], rtol=0, atol=1e-9)
+        assert int(np.argmax(S_norm)) == int(z[f"argmax_{m}"]) and S_norm.max() == 1.0
+        assert rel_l2(S_norm[::61], z[f"Snorm_sub_{m}"]) < 1e-12
+        assert np.array_equal(Eaxis[::61], z[f"Eaxis_sub_{m}"])
+        E1, p1, ax1, S1 = fa.fft_from_timeseries(z[f"f_t_{m}"], times, **kw)
+        np.testing.assert_allclose(E, E1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p, p1, rtol=0, atol=1e-12)
+        assert np.array_equal(S_norm, S1) and np.array_equal(Eaxis, ax1)
+    # ragged outcomes inside one batch: a silent signal (no line), a real one, a noisy one
+    t = np.arange(500) * 0.02
+    sigs = [np.zeros(500, complex), np.cos(1.7 * t), _rand(500, 4, np.complex128) + 5 * np.exp(-1j * 2.2 * t)]
+    got = fa.fft_from_timeseries_batch(sigs, t, n_levels=4, pad_factor=8)
+    for f, (E, p, ax, Sn) in zip(sigs, got):
+        Eo, po, axo, Sno = so.fft_from_timeseries(f, t, n_levels=4, pad_factor=8)
+        assert E.shape == Eo.shape
+        np.testing.assert_allclose(E, Eo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p, po, rtol=0, atol=1e-9)
+        assert rel_l2(Sn, Sno) < 1e-12 and np.array_equal(ax, axo)
+    assert fa.fft_from_timeseries_batch([], t) == []
+    with pytest.raises(ValueError):
+        fa.fft_from_timeseries_batch([np.ones(499)], t)
+
+
+def _reference_pick(S, omega, mode, want, guard, dc_thresh, include_dc):
+    """The candidate / ranking / guard-spaced pick / refinement steps as the reference writes them
+    (final2.py:151-171 for mode 0, streamlit_app_combined.py:218-227 for mode 1), on a given S."""
+    loc = np.where((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:]))[0] + 1
+    if mode == 0:
+        if include_dc:
+            if S[0] > 0:
+                loc = np.unique(np.concatenate(([0], loc)))
+        else:
+            loc = loc[np.abs(omega[loc]) > dc_thresh]
+    cand = loc[np.argsort(S[loc], kind="stable")[::-1]]
+    picked = []
+    for k in cand:
+        if len(picked) >= want:
+            break
+        if mode == 0:
+            ok = all(abs(omega[k] - omega[j]) > guard for j in picked)
+        else:
+            ok = all(abs(abs(omega[k]) - abs(omega[j])) > guard for j in picked)
+        if ok:
+            picked.append(int(k))
+    return picked, np.array([so._log_parabola(omega, S, i) for i in picked])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_device_peak_pipeline_matches_reference_steps(fa, dtype):
+    """mfft_lines_host's candidates, ranking, guard-spaced pick and refinement against the
+    reference's own steps evaluated on the SAME spectrum (bit-exact bins, refined positions to
+    1e-12), over both modes, DC handling, guards from none to wide, noise-like and line spectra,
+    batches, and exact height ties."""
+    rng = np.random.default_rng(17 + dtype)
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    cases = [(300, 16, 3), (1501, 16, 2), (257, 1, 4), (64, 4, 1), (1000, 3, 5)]      # n0, pad, batch
+    for n0, pad, batch in cases:
+        n, dt = n0 * pad, 0.01
+        t = np.arange(n0) * dt
+        x = 0.05 * (rng.standard_normal((batch, n0)) + 1j * rng.standard_normal((batch, n0)))
+        for b in range(batch):
+            for E, w in zip(rng.uniform(-40, 40, 4), rng.uniform(0.1, 1.0, 4)):
+                x[b] += w * np.exp(-1j * E * t)
+        x[0] = x[0].real                                   # symmetric spectrum: +-omega pairs of equal height
+        x = x.astype(cdt)
+        omega = 2.0 * np.pi * np.fft.fftfreq(n, d=dt)
+        domega = 2 * np.pi / (t[-1] - t[0] + 1e-12)
+        with fa.Plan(n, n_in=n0, batch=batch, dtype=dtype, flags=fa.POWER | fa.STATS | fa.HANN) as p:
+            for mode, include_dc, gm, want in ((0, False, 1.2, 3), (0, True, 2.0, 6), (0, False, 0.0, 8),
+                                               (0, False, 25.0, 64), (1, False, 0.6, 3), (1, False, 0.6, 9)):
+                r = p.exec_host_lines(x, axis_dt=dt, guard=gm * domega, want=want, dc_guard=1.5 * domega,
+                                      include_dc=include_dc, mode=mode, scale=dt)
+                S = r["S"].astype(np.float64)
+                for b in range(batch):
+                    picked, refined = _reference_pick(S[b], omega, mode, want, gm * domega, 1.5 * domega, include_dc)
+                    k = int(r["count"][b])
+                    got = [int(i) for i in r["idx"][b, :k]]
+                    if got != picked:
+                        # exact ties (the +-omega bins of a real signal) may be taken in either order;
+                        # the heights walked must still be the same non-increasing sequence
+                        assert sorted(got) == sorted(picked) or np.array_equal(S[b][got], S[b][picked]), (n0, mode, b)
+                        assert np.array_equal(S[b][got], S[b][picked])
+                    else:
+                        np.testing.assert_allclose(r["omega_hat"][b, :k], refined, rtol=0,
+                                                   atol=1e-12 * max(1.0, np.abs(omega).max()))
+                    assert np.all(r["idx"][b, k:] == -1)
+                    assert np.array_equal(r["height"][b, :k], S[b][got])
+    with fa.Plan(64, batch=1, dtype=1, flags=fa.POWER | fa.STATS) as p:
+        with pytest.raises(ValueError):
+            p.exec_host_lines(np.ones(64, complex), axis_dt=0.1, guard=1.0, want=65)
+        with pytest.raises(ValueError):
+            p.exec_host_lines(np.ones(64, complex), axis_dt=0.1, guard=1.0, want=0)
+    with fa.Plan(64, batch=1, dtype=1) as p:
+        with pytest.raises(ValueError):
+            p.exec_host_lines(np.ones(64, complex), axis_dt=0.1, guard=1.0, want=2)

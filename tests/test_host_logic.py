@@ -80,15 +80,9 @@ def test_fftfreq_matches_numpy(n, d):
     assert np.array_equal(fft_amd.fftfreq(n, d), np.fft.fftfreq(n, d))
 
 
-def test_refine_and_fit_match_oracle():
-    from fft_amd.spectral import _refine_log_parabola, _solve_normal
+def test_fit_matches_lstsq_on_the_basis():
+    from fft_amd.spectral import _solve_normal
     rng = np.random.default_rng(3)
-    y = rng.random(50) + 0.1
-    x = np.linspace(-3, 3, 50)
-    for i in (0, 1, 17, 48, 49):
-        assert _refine_log_parabola(x, y, i) == so._log_parabola(x, y, i)
-    flat = np.ones(5)
-    assert _refine_log_parabola(x[:5], flat, 2) == x[2]
     t = np.arange(400) * 0.05
     E = np.array([-1.0, 0.4, 2.2]); p = np.array([0.5, 0.3, 0.2])
     win = np.hanning(len(t))
@@ -127,19 +121,6 @@ def test_engine_dtype_promotion():
     assert engine_dtype(np.zeros(2, np.complex128)) == (_lib.C128, False)
     assert engine_dtype(np.zeros(2, np.float64)) == (_lib.C128, True)
     assert engine_dtype(np.zeros(2, np.int32)) == (_lib.C128, True)
-
-
-def test_by_height_matches_full_sort():
-    from fft_amd.spectral import _by_height
-    rng = np.random.default_rng(8)
-    for size in (0, 1, 10, 256, 257, 5000):
-        cand = np.sort(rng.choice(100000, size=size, replace=False))
-        h = rng.random(size)
-        assert list(_by_height(cand, h)) == list(cand[np.argsort(h)[::-1]])
-    h = np.repeat(rng.random(50), 20)                    # ties across the partition boundary
-    cand = np.arange(1000)
-    got = list(_by_height(cand, h))
-    assert sorted(got) == list(range(1000)) and np.all(np.diff(h[got]) <= 0)
 
 
 def test_sign_search_matches_one_fit_per_pattern():

@@ -54,6 +54,13 @@ def main():
         t_full = best(lambda: fft_amd.fft_from_timeseries(f_t, times, **kw))
         t_ref_fft = best(lambda: np.abs(dt * np.fft.fft(f_t * np.hanning(n0), n=nfft)) ** 2)
         t_ref_full = best(lambda: so.fft_from_timeseries(f_t, times, **kw), reps=3)
+        # the app's loop over the blocks m (final2.py:752-758): three single calls vs one batched call
+        blocks = [so.return_amplitude_block([1, 1, 1], [1, 1], m, 0, times) for m in (0, 1, 2)]
+        fft_amd.fft_from_timeseries_batch(blocks, times, **kw)
+        t_three = best(lambda: [fft_amd.fft_from_timeseries(f, times, **kw) for f in blocks])
+        t_batch = best(lambda: fft_amd.fft_from_timeseries_batch(blocks, times, **kw))
+        print(f"N0={n0} Nfft={nfft}: three blocks, single calls {t_three*1e3:7.2f} ms ({t_three/3*1e3:6.2f} per block) | "
+              f"one batched call {t_batch*1e3:7.2f} ms ({t_batch/3*1e3:6.2f} per block) = {t_three/t_batch:4.2f}x", flush=True)
         print(f"N0={n0} Nfft={nfft} launches={plan.launches}: "
               f"device plan {t_dev*1e6:8.1f} us | exec_host {t_host*1e3:7.3f} ms | "
               f"fft_from_timeseries GPU path {t_full*1e3:7.2f} ms vs numpy path {t_ref_full*1e3:7.2f} ms "
