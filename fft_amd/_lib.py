@@ -62,6 +62,17 @@ SIGNATURES = {
     "mfft_transpose": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "mfft_swap_axes": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "mfft_twiddle_tile": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+    "mfft_comm_unique_id": (_int, [_vp]),
+    "mfft_comm_init_rank": (_int, [ctypes.POINTER(_vp), _int, _int, _vp]),
+    "mfft_comm_init_local": (_int, [ctypes.POINTER(_vp), _int]),
+    "mfft_comm_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "mfft_comm_destroy": (_int, [_vp]),
+    "mfft_comm_exchange": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mfft_plan_2d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int]),
+    "mfft_plan_1d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int]),
+    "mfft_dist_exec": (_int, [_vp, _vp, _vp, _vp]),
+    "mfft_dist_plan_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_i64)]),
+    "mfft_dist_plan_destroy": (_int, [_vp]),
 }
 
 _lib = None

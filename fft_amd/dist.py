@@ -156,6 +156,79 @@ def _chunk_count(requested, rows, world):
     return c
 
 
+# --------------------------------------------------------------------------- C ABI route
+
+class CComm:
+    """Communicator of the C ABI (mfft_comm): RCCL inside libmfft.so, no torch.distributed on the
+    data path.  `fft2_slab` / `fft1d_fourstep` given a CComm run as one mfft_dist_exec call."""
+
+    def __init__(self, handle, world, rank):
+        self._h, self.world, self.rank, self.backend = handle, int(world), int(rank), "mfft"
+        self._plans = {}
+        self.timings = None
+
+    @classmethod
+    def from_unique_id(cls, world, rank, uid: bytes):
+        """Join an RCCL communicator (collective); `uid` comes from CComm.unique_id() on rank 0."""
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(uid), 128)
+        _lib.check(_lib.load().mfft_comm_init_rank(ctypes.byref(h), int(world), int(rank), buf))
+        return cls(h, world, rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().mfft_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, group=None):
+        """One rank per process under torch.distributed: rank 0's id is broadcast through the
+        process group (any backend), then every rank joins with its current device."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(box, src=src, group=group)
+        return cls.from_unique_id(world, rank, box[0])
+
+    @classmethod
+    def local(cls, nranks):
+        """`nranks` ranks sharing the current device inside this process (one host thread each)."""
+        arr = (ctypes.c_void_p * int(nranks))()
+        _lib.check(_lib.load().mfft_comm_init_local(arr, int(nranks)))
+        return [cls(ctypes.c_void_p(arr[i]), nranks, i) for i in range(int(nranks))]
+
+    def plan(self, kind, a0, a1, dtype, option, chunks):
+        key = (kind, int(a0), int(a1), int(dtype), int(bool(option)), chunks)
+        h = self._plans.get(key)
+        if h is None:
+            h = ctypes.c_void_p()
+            fn = _lib.load().mfft_plan_2d_dist if kind == "2d" else _lib.load().mfft_plan_1d_dist
+            _lib.check(fn(ctypes.byref(h), self._h, int(a0), int(a1), int(dtype), int(bool(option)),
+                          int(chunks) if chunks else 0))
+            self._plans[key] = h
+        return h
+
+    def run(self, kind, src, a0, a1, option, chunks):
+        import torch
+        dtype = HipOps._dtype_of(src)
+        h = self.plan(kind, a0, a1, dtype, option, chunks)
+        out = torch.empty_like(src)
+        _lib.check(_lib.load().mfft_dist_exec(h, src.data_ptr(), out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream or None))
+        return out
+
+    def close(self):
+        lib = _lib.load()
+        for h in self._plans.values():
+            lib.mfft_dist_plan_destroy(h)
+        self._plans.clear()
+        if self._h is not None:
+            lib.mfft_comm_destroy(self._h)
+            self._h = None
+
+
 # --------------------------------------------------------------------------- local operations
 
 class HipOps:
@@ -276,6 +349,8 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
     R, W = n0 // P, n1 // P
     if a_local.numel() != R * n1:
         raise ValueError("a_local has the wrong size for this rank's slab")
+    if isinstance(comm, CComm):                    # the whole decomposition inside libmfft.so, RCCL exchanges
+        return comm.run("2d", a_local, n0, n1, restore_layout, chunks)
     bufs = _Buffers(ops, R * n1, a_local)
 
     # row FFTs; bin k of local row i is stored at [k // W][i][k % W]: already packed per destination
@@ -345,6 +420,8 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
     R1, W2 = n1 // P, n2 // P
     if x_local.numel() != R1 * n2:
         raise ValueError("x_local has the wrong size for this rank's chunk")
+    if isinstance(comm, CComm):
+        return comm.run("1d", x_local, n1, n2, natural_order, chunks)
     bufs = _Buffers(ops, R1 * n2, x_local)
 
     # pack: local rows j1 (R1 x P x W2) -> [s][i][c]; destination s owns columns [s*W2, (s+1)*W2)

@@ -256,6 +256,56 @@ int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t 
 int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
                       int64_t n_total, int dtype, void* stream);
 
+/* ---- multi-GPU decompositions -----------------------------------------------------------
+ * No counterpart in the reference (it never leaves one process): BASELINE configurations 4 and 5,
+ * np.fft.fft2 of an n0 x n1 array held in row slabs and np.fft.fft of ONE signal of n1*n2 points
+ * held in contiguous chunks, one rank per GPU.  Exchanges are groups of RCCL point-to-point
+ * transfers over xGMI, cut into row chunks and overlapped with the transforms that produce or
+ * consume them; packing and unpacking happen inside the transform kernels' own loads and stores.
+ * RCCL (librccl.so.1) is loaded on first use; single-GPU callers never load it.
+ *
+ * Communicators.  mfft_comm_unique_id: rank 0 makes a 128-byte id and hands it to every rank by
+ * any means (a file, MPI, torch.distributed); mfft_comm_init_rank: every rank, with its device
+ * current, joins (ncclCommInitRank; collective).  mfft_comm_init_local: `nranks` ranks that share
+ * the CURRENT device inside one process, exchanging by device copies -- a rehearsal of the
+ * multi-rank paths on one GPU; each rank must then be driven by a host thread of its own, because
+ * an exchange waits for all ranks to arrive. */
+typedef struct mfft_comm_s* mfft_comm;
+typedef struct mfft_dist_plan_s* mfft_dist_plan;
+int mfft_comm_unique_id(void* id128);
+int mfft_comm_init_rank(mfft_comm* out, int world, int rank, const void* id128);
+int mfft_comm_init_local(mfft_comm* out /* nranks handles */, int nranks);
+int mfft_comm_info(mfft_comm comm, int* world, int* rank);
+int mfft_comm_destroy(mfft_comm comm);
+/* The exchange primitive itself: block d_send[p] (`bytes` bytes, device memory) goes to rank p and
+ * d_recv[p] receives what rank p sends here -- an all-to-all with caller-chosen block addresses,
+ * one ncclSend / ncclRecv pair per peer in one group.  Enqueued on `stream`; collective. */
+int mfft_comm_exchange(mfft_comm comm, const void* const* d_send, void* const* d_recv, int64_t bytes, void* stream);
+
+/* 2-D forward DFT of an n0 x n1 array distributed by row slabs.  Input: this rank's n0/P
+ * consecutive rows (row-major, (n0/P)*n1 elements).  Output, same size:
+ *   restore_layout == 0 (one exchange):  all n0 rows of this rank's n1/P columns,
+ *                                        out[k0*(n1/P) + c] = F[k0][rank*(n1/P) + c];
+ *   restore_layout != 0 (two exchanges): the input's own layout, out[i*n1 + k1] = F[rank*(n0/P) + i][k1].
+ * Both dimensions must divide by the number of ranks; shapes the column-batched passes do not
+ * serve return MFFT_E_UNSUPPORTED.  chunks: row chunks per exchange (<= 0: 4; 1 with one rank). */
+int mfft_plan_2d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n0, int64_t n1, int dtype,
+                      int restore_layout, int chunks);
+
+/* Forward DFT of ONE signal of n = n1*n2 points (four-step split) distributed in contiguous
+ * chunks.  Input: this rank's n/P consecutive samples.  Output, n/P elements:
+ *   natural_order != 0 (three exchanges): X[rank*n/P + m];
+ *   natural_order == 0 (two exchanges):   out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2]. */
+int mfft_plan_1d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n1, int64_t n2, int dtype,
+                      int natural_order, int chunks);
+
+/* Run a distributed plan on device buffers (d_in != d_out; d_in is not modified), kernels on
+ * `stream`, exchanges on a stream of the plan ordered against it by events.  Asynchronous;
+ * collective: every rank of the communicator calls it with its own plan, in the same order. */
+int mfft_dist_exec(mfft_dist_plan plan, const void* d_in, void* d_out, void* stream);
+int mfft_dist_plan_info(mfft_dist_plan plan, int* chunks, int64_t* workspace_bytes);
+int mfft_dist_plan_destroy(mfft_dist_plan plan);
+
 #ifdef __cplusplus
 }
 #endif
