@@ -51,6 +51,13 @@ def parse():
     ap.add_argument("--no-dist-configs", action="store_true",
                     help="with several ranks: skip the sharded 2-D / long 1-D transforms (BASELINE configs 4, 5) "
                          "that follow the batch-sharded headline")
+    ap.add_argument("--dist-configs", action="store_true",
+                    help="run the sharded-transform section even with one rank (both routes; a plumbing check)")
+    ap.add_argument("--no-dist-c-abi", action="store_true",
+                    help="with several ranks over RCCL: skip the second run of configs 4 and 5 through the C ABI's own "
+                         "distributed plans (a watchdog abandons that leg after --c-abi-timeout seconds and still "
+                         "prints the line)")
+    ap.add_argument("--c-abi-timeout", type=float, default=240.0)
     ap.add_argument("--dist-n2d", type=int, default=16384, help="side of the sharded 2-D transform (config 4)")
     ap.add_argument("--dist-log2n1d", type=int, default=0,
                     help="log2 length of the sharded 1-D transform (config 5); 0 = 31 on 8 ranks, else 28 + log2(ranks)")
@@ -190,7 +197,7 @@ def secondary_configs(with_cpu):
         top = 31 if free >= 180 * (1 << 30) else 28
         # the shorter lengths are what 2- and 4-GPU jobs run (2^(28 + log2 ranks)): their one-GPU figures
         for lg in [q for q in (28, 29, 30) if q < top] + [top]:
-            n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+            n1, n2 = fd.fourstep_factors(lg)
             x = torch.empty(n1 * n2, dtype=torch.complex128, device="cuda")
             xr = torch.view_as_real(x)
             for lo in range(0, n1 * n2, 1 << 27):
@@ -218,14 +225,16 @@ def secondary_configs(with_cpu):
     return out
 
 
-def dist_configs(args, world, rank):
+def dist_configs(args, world, rank, c_abi=False):
     """BASELINE configs 4 and 5 over the ranks of this job -- the sharded transforms with real
     exchange steps (fft_amd/dist.py: row/column slabs with one or two all-to-alls; the four-step
     split of one long signal with two or three).  Every entry: ms per transform (max over ranks,
     barrier-bracketed, best of a few brackets), whole-job GFLOP/s, the duration of each exchange
     on this rank (events around each collective / chunked exchange), the ratio to the one-GPU
     figure of the same transform when profiles/one_gpu_reference.json has one, and a correctness
-    check of sampled bins against the DFT evaluated directly in float64 over all ranks' data."""
+    check of sampled bins against the DFT evaluated directly in float64 over all ranks' data.
+    c_abi: run the transforms through the C ABI's own distributed plans (RCCL called from inside
+    libmfft.so, every exchange chunked and overlapped) instead of the torch.distributed route."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -233,7 +242,10 @@ def dist_configs(args, world, rank):
 
     comm, ops = fd.Comm(), fd.HipOps()
     P = comm.world
+    xcomm = fd.CComm.from_torch() if c_abi else comm          # the communicator the transforms use
     out = {"world_size": P, "backend": comm.backend, "transport": "RCCL" if comm.backend == "nccl" else comm.backend,
+           "route": "C ABI (mfft_plan_2d_dist / mfft_plan_1d_dist, RCCL send/recv groups)" if c_abi
+                    else "fft_amd.dist over torch.distributed",
            "chunks_first_exchange": fd._chunk_count(None, 1 << 20, P)}
     one_gpu = {}
     rpath = os.path.join(ROOT, "profiles", "one_gpu_reference.json")
@@ -311,7 +323,7 @@ def dist_configs(args, world, rank):
 
         want = allsum(torch.view_as_real(torch.stack([direct(k0, k1) for k0, k1 in bins])).contiguous())
         for restore in (False, True):
-            f = fd.fft2_slab(a, n, n, comm, ops, restore_layout=restore)
+            f = fd.fft2_slab(a, n, n, xcomm, ops, restore_layout=restore)
             got = torch.zeros(len(bins), dtype=torch.complex128, device="cuda")
             for i, (k0, k1) in enumerate(bins):
                 if restore and k0 // R == rank:
@@ -321,7 +333,7 @@ def dist_configs(args, world, rank):
             got = allsum(torch.view_as_real(got).contiguous())
             err = float(torch.max(torch.linalg.vector_norm(got - want, dim=-1)).item()) / rms
             del f
-            t, ex = bracket(lambda: fd.fft2_slab(a, n, n, comm, ops, restore_layout=restore), inner=5, reps=3)
+            t, ex = bracket(lambda: fd.fft2_slab(a, n, n, xcomm, ops, restore_layout=restore), inner=5, reps=3)
             name = f"config4_2d_{n}x{n}_c64" + ("_row_slabs_out" if restore else "_column_slabs_out")
             out[name] = entry(t, ex, n * n, 2 * math.log2(n), 8, f"config4_2d_{n}", scaling="strong",
                               all_to_alls=2 if restore else 1, verified_max_err_over_rms=err, verified_bins=len(bins))
@@ -331,12 +343,16 @@ def dist_configs(args, world, rank):
     except Exception as exc:                                  # noqa: BLE001 - never sink the headline
         out["config4_error"] = repr(exc)[:300]
     ops.close()
+    if c_abi:
+        for h in xcomm._plans.values():
+            fd._lib.load().mfft_dist_plan_destroy(h)
+        xcomm._plans.clear()
     torch.cuda.empty_cache()
 
     # ---- config 5: one long complex128 signal, four-step ----------------------------------------
     try:
         lg = args.dist_log2n1d or (31 if P >= 8 else 28 + int(round(math.log2(P))))
-        n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+        n1, n2 = fd.fourstep_factors(lg)
         n = n1 * n2
         cnt = n // P
         g = torch.Generator(device="cuda").manual_seed(50 + rank)
@@ -362,7 +378,7 @@ def dist_configs(args, world, rank):
 
         want = allsum(torch.view_as_real(torch.stack([direct1(k) for k in ks])).contiguous())
         for natural in (True, False):
-            y = fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=natural)
+            y = fd.fft1d_fourstep(x, n1, n2, xcomm, ops, natural_order=natural)
             got = torch.zeros(len(ks), dtype=torch.complex128, device="cuda")
             for i, k in enumerate(ks):
                 if natural:
@@ -375,7 +391,7 @@ def dist_configs(args, world, rank):
             got = allsum(torch.view_as_real(got).contiguous())
             err = float(torch.max(torch.linalg.vector_norm(got - want, dim=-1)).item()) / rms
             del y
-            t, ex = bracket(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=natural), inner=2, reps=2)
+            t, ex = bracket(lambda: fd.fft1d_fourstep(x, n1, n2, xcomm, ops, natural_order=natural), inner=2, reps=2)
             name = f"config5_1d_2pow{lg}_c128" + ("_natural_order" if natural else "_transposed_order")
             out[name] = entry(t, ex, n, lg, 16, f"config5_1d_2pow{lg}", scaling="strong",
                               all_to_alls=3 if natural else 2, verified_max_err_over_rms=err, verified_bins=len(ks))
@@ -385,6 +401,8 @@ def dist_configs(args, world, rank):
     except Exception as exc:                                  # noqa: BLE001
         out["config5_error"] = repr(exc)[:300]
     ops.close()
+    if c_abi:
+        xcomm.close()
     torch.cuda.empty_cache()
     return out
 
@@ -509,12 +527,33 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and n == N_POINTS and batch == BATCH:
         torch.cuda.empty_cache()
         line["other_configs"] = secondary_configs(with_cpu=not args.no_cpu)
-    if distributed and not args.no_dist_configs:
+    if (distributed or args.dist_configs) and not args.no_dist_configs:
         # every rank takes part; rank 0 reports
         torch.cuda.empty_cache()
         dc = dist_configs(args, world, rank)
         if rank == 0:
             line["dist_configs"] = dc
+        if (args.backend == "nccl" or not distributed) and not args.no_dist_c_abi:
+            # Same configs through libmfft's own RCCL calls.  This route has run on RCCL with one rank
+            # and on several in-process ranks only, so it is fenced: if it has not finished in time every
+            # rank leaves (rank 0 after printing the line with what the job measured so far).
+            import threading
+
+            def abandon():
+                if rank == 0:
+                    line["dist_configs_c_abi"] = {"error": f"abandoned after {args.c_abi_timeout:.0f} s"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+            timer = threading.Timer(args.c_abi_timeout, abandon)
+            timer.daemon = True
+            timer.start()
+            try:
+                dcc = dist_configs(args, world, rank, c_abi=True)
+            except Exception as exc:                          # noqa: BLE001
+                dcc = {"error": repr(exc)[:300]}
+            timer.cancel()
+            if rank == 0:
+                line["dist_configs_c_abi"] = dcc
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:

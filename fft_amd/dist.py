@@ -186,6 +186,8 @@ class CComm:
         """One rank per process under torch.distributed: rank 0's id is broadcast through the
         process group (any backend), then every rank joins with its current device."""
         import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return cls.from_unique_id(1, 0, cls.unique_id())        # a single process: one rank
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         box = [cls.unique_id() if rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
@@ -383,13 +385,34 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
     # cur[k0][c] = F[k0][rank*W + c]
     if not restore_layout:
         return cur
-    # rows [s*R, (s+1)*R) belong to rank s: the per-destination chunks are already contiguous
-    res = comm.all_to_all(bufs.free(cur), cur, "columns->rows")     # res[s][i][c] = F[rank*R + i][s*W + c]
     if P == 1:
-        return res
-    out = bufs.free(res)
-    ops.swap_axes(res, out, a=P, b=R, w=W)         # out[i][s][c]: (R x n1)
+        return cur
+    # way back: rows [s*R, (s+1)*R) belong to rank s and are contiguous; they travel in row chunks, and
+    # a chunk that has arrived ([s][i][c], P x Rc x W) is unpacked into its Rc output rows while the
+    # next one is on the links
+    C2 = _chunk_count(chunks, R, P)
+    Rc, piece = R // C2, (R // C2) * W
+    res = bufs.free(cur)
+    out = ops.empty(R * n1, a_local)
+    pending = []
+    for c in range(C2):
+        sends = [cur[(s * R + c * Rc) * W:(s * R + c * Rc) * W + piece] for s in range(P)]
+        recvs = [res[(c * P + r) * piece:(c * P + r + 1) * piece] for r in range(P)]
+        pending.append(comm.start_exchange(sends, recvs, f"columns->rows[{c}/{C2}]"))
+    for c, h in enumerate(pending):
+        h.wait()
+        ops.swap_axes(res[c * P * piece:], out[c * Rc * n1:], a=P, b=Rc, w=W)     # out[i][s][c]: Rc rows of n1
     return out
+
+
+def fourstep_factors(log2n: int, complex128: bool = True):
+    """(n1, n2) with n1*n2 = 2^log2n for `fft1d_fourstep`: n2 as long as ONE LDS-resident kernel
+    transforms (8192 complex128 / 16384 complex64 points), so the row step is a single pass over the
+    data and the strided column step takes the rest in two; an even split makes both steps two-pass
+    (measured at 2^31 complex128 on 8 ranks' shapes: 8.2 -> 6.4 ms of local work per GPU)."""
+    cap = 13 if complex128 else 14
+    l2 = min(cap, log2n // 2)
+    return 1 << (log2n - l2), 1 << l2
 
 
 # --------------------------------------------------------------------------- large 1-D four-step
@@ -457,17 +480,46 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
         ops.twiddle(tmp, rows=W2, cols=n1, r0=comm.rank * W2, c0=0, n_total=n)
         cur = bufs.free(tmp, x_local)
         ops.transpose(tmp, cur, rows=W2, cols=n1)  # (n1 x W2)
-    # rows k1 in [s*R1, (s+1)*R1) belong to rank s: chunks already contiguous
-    res = comm.all_to_all(bufs.free(cur, x_local), cur, "columns->rows")   # res[s][i][c] = A[k1 = rank*R1 + i][j2 = s*W2 + c]
-    out = bufs.free(res, x_local)
-    # n2-point FFT over j2 for each local row i: sample j2 sits at [j2 // W2][i][j2 % W2]
-    seg_in = (W2, W2, R1 * W2)
+    seg_in = (W2, W2, R1 * W2)      # sample j2 of local row i sits at [j2 // W2][i][j2 % W2]
+    if P == 1:
+        out = bufs.free(cur, x_local)
+        ops.fft(cur, out, n=n2, batch=R1)
+        if not natural_order:
+            return out
+        res = bufs.free(out, x_local)
+        ops.transpose(out, res, rows=n1, cols=W2)
+        return res
+    # Second exchange + n2-point transforms, chunked over this rank's rows k1: rows k1 in [s*R1, (s+1)*R1)
+    # belong to rank s and are contiguous; the blocks of chunk c (rows [c*Rc, +Rc) from every peer) are
+    # transformed while chunk c + 1 travels.  For natural order bin k2 of row i goes to
+    # [k2 // W2][i][k2 % W2] (the owner of natural index k2*n1 + k1) and chunk c leaves for its owners
+    # -- into the regions of `res` that the transform has just consumed -- while chunk c + 1 is transformed.
+    C2 = _chunk_count(chunks, R1, P)
+    Rc, piece = R1 // C2, (R1 // C2) * W2
+    res = bufs.free(cur, x_local)
+    extra = ops.empty(R1 * n2, x_local)
+
+    def second(c):
+        sends = [cur[(s * R1 + c * Rc) * W2:(s * R1 + c * Rc) * W2 + piece] for s in range(P)]
+        recvs = [res[r * R1 * W2 + c * piece:r * R1 * W2 + (c + 1) * piece] for r in range(P)]
+        return comm.start_exchange(sends, recvs, f"columns->rows[{c}/{C2}]")
+
+    handle, third = second(0), []
+    for c in range(C2):
+        ahead = second(c + 1) if c + 1 < C2 else None
+        handle.wait()
+        if natural_order:
+            ops.fft(res[c * piece:], extra[c * piece:], n=n2, batch=Rc, in_layout=seg_in, out_layout=seg_in)
+            sends = [extra[s * R1 * W2 + c * piece:s * R1 * W2 + (c + 1) * piece] for s in range(P)]
+            recvs = [res[r * R1 * W2 + c * piece:r * R1 * W2 + (c + 1) * piece] for r in range(P)]
+            third.append(comm.start_exchange(sends, recvs, f"natural order[{c}/{C2}]"))
+        else:
+            ops.fft(res[c * piece:], extra[c * Rc * n2:], n=n2, batch=Rc, in_layout=seg_in)
+        handle = ahead
     if not natural_order:
-        ops.fft(res, out, n=n2, batch=R1, in_layout=seg_in)
-        return out
-    # bin k2 of local row i goes to [k2 // W2][i][k2 % W2] (owner of natural index k2*n1 + k1)
-    ops.fft(res, out, n=n2, batch=R1, in_layout=seg_in, out_layout=seg_in)
-    res = comm.all_to_all(bufs.free(out, x_local), out, "natural order")   # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: (n1 x W2)
-    out = bufs.free(res, x_local)
-    ops.transpose(res, out, rows=n1, cols=W2)      # -> (W2 x n1) = natural-order chunk
-    return out
+        return extra                               # out[i*n2 + k2] = X[(rank*R1 + i) + n1*k2]
+    for h in third:
+        h.wait()
+    # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: an (n1 x W2) matrix whose transpose is the natural-order chunk
+    ops.transpose(res, cur, rows=n1, cols=W2)
+    return cur

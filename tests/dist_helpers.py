@@ -111,8 +111,9 @@ def worker(rank, world, port, use_gpu, results_dir):
                     out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False, chunks=chunks)
                     out = out.cpu().numpy().reshape(n0, W)
                     errs[f"fft2_cols_{tag}_{n0}_{chunks}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
-                out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True).cpu().numpy().reshape(R, n1)
-                errs[f"fft2_rows_{tag}_{n0}"] = rel_l2(out, F[rank * R:(rank + 1) * R])
+                for chunks in (1, 2, 3, None):                   # the return exchange is chunked as well
+                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True, chunks=chunks)
+                    errs[f"fft2_rows_{tag}_{n0}_{chunks}"] = rel_l2(out.cpu().numpy().reshape(R, n1), F[rank * R:(rank + 1) * R])
                 assert np.array_equal(mine.cpu().numpy(), A[rank * R:(rank + 1) * R].reshape(-1)), "input clobbered"
 
             # ---- 1-D four-step ---------------------------------------------------------
@@ -122,8 +123,9 @@ def worker(rank, world, port, use_gpu, results_dir):
                 X = np.fft.fft(x)
                 chunk = n // world
                 mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
-                out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True).cpu().numpy()
-                errs[f"fft1d_N_{tag}_{n1f}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
+                for chunks in (1, 2, 3, None):                   # second and third exchange chunked around the row transforms
+                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True, chunks=chunks).cpu().numpy()
+                    errs[f"fft1d_N_{tag}_{n1f}_{chunks}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
                 R1 = n1f // world
                 want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
                 for chunks in (1, 2, 3, None):

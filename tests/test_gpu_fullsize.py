@@ -51,7 +51,7 @@ def test_cfg5_one_signal_2pow31_c128():
     free, _ = torch.cuda.mem_get_info()
     if free < 180 * (1 << 30):
         pytest.skip("needs about 170 GiB of free device memory")
-    n1, n2 = 1 << 16, 1 << 15
+    n1, n2 = fd.fourstep_factors(31)                                # 2^18 x 2^13
     n = n1 * n2
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.empty(n, dtype=torch.complex128, device="cuda")

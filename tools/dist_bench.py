@@ -64,8 +64,7 @@ def main():
     del a
     # ---- 1-D four-step, complex128 -------------------------------------------------------
     lg = args.log2n1d or min(31, 28 + int(math.log2(P)))
-    n1 = 1 << ((lg + 1) // 2)
-    n2 = 1 << (lg // 2)
+    n1, n2 = fd.fourstep_factors(lg)
     x = torch.view_as_complex(torch.randn(((n1 * n2) // P, 2), dtype=torch.float64, device="cuda"))
     for natural in (False, True):
         t = timeit(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=natural), comm, reps=3)

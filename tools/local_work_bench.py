@@ -77,7 +77,7 @@ def main():
                     label = "natural layout" if restore else "column slabs"
                 else:
                     lg = args.log2n
-                    n1, n2 = 1 << ((lg + 1) // 2), 1 << (lg // 2)
+                    n1, n2 = fd.fourstep_factors(lg)
                     if (n1 * n2 // P) * 16 * 5 > 250 * (1 << 30):
                         continue                      # does not fit one GPU at this rank count
                     local = torch.view_as_complex(torch.randn((n1 * n2 // P, 2), dtype=torch.float64, device="cuda"))
