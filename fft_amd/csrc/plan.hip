@@ -598,6 +598,13 @@ struct Plan {
     int64_t workspace = 0;
     int launches = 1;
     std::mutex mu;
+    // Executions of a plan that owns per-execution state (pass workspaces, the chirp-z convolution
+    // buffer, the demodulation table) are ordered on the device as well: an execution on another
+    // stream waits for the previous one's completion event.
+    std::mutex order_mu;
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
 };
 
 // symmetric Hann window of m samples, np.hanning's formula, evaluated in long double
@@ -624,7 +631,7 @@ static void plan_free(Plan* p)
         if (q) (void)hipFree(q);
     for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines})
         if (q) (void)hipHostFree(q);
-    for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1]})
+    for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1], p->last_done})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {p->s_run, p->s_out})
         if (st) (void)hipStreamDestroy(st);
@@ -850,15 +857,18 @@ static int pipe_prepare(Plan* p, size_t in_row, size_t out_row)
     const size_t row = in_row > out_row ? in_row : out_row;
     int64_t slab = (int64_t)(target / row);
     if (slab < 1) slab = 1;
-    for (int q = 0; q < 2; ++q) {
-        MFFT_HIP(hipHostMalloc(&p->pin_in[q], (size_t)slab * in_row, hipHostMallocDefault));
-        MFFT_HIP(hipHostMalloc(&p->pin_out[q], (size_t)slab * out_row, hipHostMallocDefault));
-        MFFT_HIP(hipEventCreateWithFlags(&p->ev_in[q], hipEventDisableTiming));
-        MFFT_HIP(hipEventCreateWithFlags(&p->ev_run[q], hipEventDisableTiming));
-        MFFT_HIP(hipEventCreateWithFlags(&p->ev_out[q], hipEventDisableTiming));
+    // handles that already exist (an earlier attempt that failed part-way) are kept, not overwritten
+    hipError_t e = hipSuccess;
+    for (int q = 0; q < 2 && e == hipSuccess; ++q) {
+        if (!p->pin_in[q]) e = hipHostMalloc(&p->pin_in[q], (size_t)slab * in_row, hipHostMallocDefault);
+        if (e == hipSuccess && !p->pin_out[q]) e = hipHostMalloc(&p->pin_out[q], (size_t)slab * out_row, hipHostMallocDefault);
+        if (e == hipSuccess && !p->ev_in[q]) e = hipEventCreateWithFlags(&p->ev_in[q], hipEventDisableTiming);
+        if (e == hipSuccess && !p->ev_run[q]) e = hipEventCreateWithFlags(&p->ev_run[q], hipEventDisableTiming);
+        if (e == hipSuccess && !p->ev_out[q]) e = hipEventCreateWithFlags(&p->ev_out[q], hipEventDisableTiming);
     }
-    MFFT_HIP(hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking));
-    MFFT_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    if (e == hipSuccess && !p->s_run) e = hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking);
+    if (e == hipSuccess && !p->s_out) e = hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_fail(e, "pipelined staging", __FILE__, __LINE__);
     p->pipe_slab = slab;
     return MFFT_OK;
 }
@@ -999,7 +1009,8 @@ int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, 
     const uint32_t known = MFFT_HANN | MFFT_POWER | MFFT_DEMOD | MFFT_REAL_IN | MFFT_STATS | MFFT_INVERSE;
     if (flags & ~known) { set_error("unknown flag bits"); return MFFT_E_INVALID; }
     if ((flags & MFFT_STATS) && !(flags & MFFT_POWER)) { set_error("MFFT_STATS needs MFFT_POWER"); return MFFT_E_INVALID; }
-    if (!layout_ok(in_layout, n) || !layout_ok(out_layout, n)) { set_error("bad layout descriptor"); return MFFT_E_INVALID; }
+    if (!layout_ok(in_layout, n_in) || !layout_ok(out_layout, n)) { set_error("bad layout descriptor"); return MFFT_E_INVALID; }
+    if (n == 1 && out_layout && out_layout->batch_stride > 1) { set_error("1-point plans take dense output only"); return MFFT_E_UNSUPPORTED; }
     if (mfft_device_count() < 0) return MFFT_E_NODEVICE;
     Plan* p = new (std::nothrow) Plan;
     if (!p) { set_error("host allocation failed"); return MFFT_E_NOMEM; }
@@ -1078,7 +1089,21 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale, doubl
     if ((p->flags & MFFT_STATS) && !d_stats) { set_error("plan has MFFT_STATS but d_stats is null"); return MFFT_E_INVALID; }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
-    return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool shared_state = p->kind == Plan::CHIRPZ || (p->flags & MFFT_DEMOD) ||
+                              ((p->kind == Plan::POW2 || p->kind == Plan::COLUMNS) && !p->eng.single);
+    if (!shared_state) return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
+    std::lock_guard<std::mutex> order(p->order_mu);
+    if (!p->last_done) MFFT_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
+    const bool other_stream = p->have_last && p->last_stream != s;
+    if (other_stream) MFFT_HIP(hipStreamWaitEvent(s, p->last_done, 0));
+    const int rc = plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
+    if (rc == MFFT_OK) {
+        MFFT_HIP(hipEventRecord(p->last_done, s));
+        p->last_stream = s;
+        p->have_last = true;
+    }
+    return rc;
 }
 
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu, double t0,

@@ -25,6 +25,23 @@ def _addr(buf) -> int:
     raise TypeError(f"cannot take a device address from {type(buf).__name__}")
 
 
+def _check_buffer(buf, count: int, np_dtype, what: str, device=None):
+    """Shape / dtype / layout check of a tensor-like device buffer (anything with numel(),
+    dtype, is_contiguous()); plain integer addresses cannot be checked and pass through.  A wrong
+    buffer would otherwise be read or written out of bounds on the GPU."""
+    if buf is None or isinstance(buf, int) or not hasattr(buf, "numel"):
+        return
+    if not buf.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    if int(buf.numel()) < count:
+        raise ValueError(f"{what} holds {int(buf.numel())} elements, the plan needs {count}")
+    name = str(buf.dtype).replace("torch.", "")
+    if name != np.dtype(np_dtype).name:
+        raise ValueError(f"{what} has dtype {name}, the plan needs {np.dtype(np_dtype).name}")
+    if not getattr(buf, "is_cuda", True):
+        raise ValueError(f"{what} must live in device memory")
+
+
 class Plan:
     """One batched 1-D transform configuration (see include/mfft.h: mfft_plan_1d)."""
 
@@ -39,6 +56,7 @@ class Plan:
         self.dtype = int(dtype)
         self.flags = int(flags)
         self._h = ctypes.c_void_p()
+        self._has_layout = in_layout is not None or out_layout is not None
         lin = _lib.Layout(*[int(v) for v in in_layout]) if in_layout is not None else None
         lout = _lib.Layout(*[int(v) for v in out_layout]) if out_layout is not None else None
         _lib.check(lib.mfft_plan_1d_layout(ctypes.byref(self._h), self.n, self.n_in, self.batch,
@@ -79,9 +97,17 @@ class Plan:
     # -- execution ------------------------------------------------------------
     def exec(self, d_in, d_out, scale: float = 1.0, mu: float = 0.0, t0: float = 0.0, dt: float = 1.0,
              d_stats=None, stream: int = 0):
-        """Asynchronous execution on device buffers (addresses or tensors)."""
+        """Asynchronous execution on device buffers (addresses or tensors).  Tensors are checked
+        against the plan (dense plans: batch*n_in elements in, batch*n out; plans with a layout
+        describe their own extents and are not checked)."""
         if self._h is None:
             raise ValueError("plan already destroyed")
+        if not getattr(self, "_has_layout", False):
+            inner = getattr(self, "inner", 1)
+            _check_buffer(d_in, self.batch * self.n_in * inner, self.in_dtype, "d_in")
+            _check_buffer(d_out, self.batch * self.n * inner, self.out_dtype, "d_out")
+        if self.flags & _lib.STATS:
+            _check_buffer(d_stats, 3 * self.batch, np.float64, "d_stats")
         _lib.check(_lib.load().mfft_exec(self._h, _addr(d_in), _addr(d_out), float(scale), float(mu),
                                          float(t0), float(dt), _addr(d_stats), int(stream) or None))
 

@@ -14,9 +14,11 @@
  * Conventions: all functions return 0 (MFFT_OK) or a negative MFFT_E_* code and
  * never throw.  mfft_last_error() returns a thread-local detail string.  Plans
  * are bound to the HIP device that was current when they were created.  A plan
- * may be executed from several host threads, but two executions of the SAME plan
- * must not overlap (they share the plan's workspace); distinct plans are
- * independent.  "d_" pointers are device memory, "h_" pointers host memory.
+ * may be executed from several host threads and on several streams: executions
+ * of the SAME plan that share its workspace (multi-pass, chirp-z and
+ * demodulating plans) are ordered by the library, on the host and -- through a
+ * completion event -- on the device; distinct plans are independent.  "d_"
+ * pointers are device memory, "h_" pointers host memory.
  */
 #ifndef MFFT_H
 #define MFFT_H

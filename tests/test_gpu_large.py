@@ -222,3 +222,60 @@ def test_in_place_complex_transforms(fa, dtype):
         p.exec(d, d, stream=stream)
         torch.cuda.synchronize()
     assert rel_l2(d.cpu().numpy(), np.fft.fft(x.astype(np.complex128) * np.hanning(n))) < TOL[dtype]
+
+
+@pytest.mark.parametrize("n", [1 << 16, 24016])
+def test_one_plan_two_streams_two_threads(fa, n):
+    """A cached plan is shared by every thread of the process.  Multi-pass and chirp-z plans keep
+    per-execution state (pass workspaces, the convolution buffer), so executions issued from two
+    threads on two streams must be ordered by the library on the device, not only on the host."""
+    import threading
+    import torch
+    torch.cuda.set_device(0)
+    batch = 4
+    plan = fa.Plan(n, batch=batch, dtype=fa.C128)
+    xs = [_rand((batch, n), 40 + i, np.complex128) for i in range(2)]
+    refs = [np.fft.fft(x) for x in xs]
+    errs = []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d_x = torch.from_numpy(xs[i]).cuda()
+                d_y = torch.empty_like(d_x)
+                for _ in range(25):
+                    plan.exec(d_x, d_y, stream=st.cuda_stream)
+                st.synchronize()
+                errs.append(rel_l2(d_y.cpu().numpy(), refs[i]))
+        except Exception as e:                                            # noqa: BLE001
+            errs.append(repr(e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    plan.destroy()
+    assert len(errs) == 2 and all(isinstance(e, float) and e < 1e-12 for e in errs), errs
+
+
+def test_device_buffers_are_checked_against_the_plan(fa):
+    import torch
+    torch.cuda.set_device(0)
+    with fa.Plan(256, batch=4, dtype=fa.C64, flags=fa.POWER | fa.STATS) as p:
+        x = torch.zeros((4, 256), dtype=torch.complex64, device="cuda")
+        s = torch.zeros((4, 256), dtype=torch.float32, device="cuda")
+        st = torch.zeros((4, 3), dtype=torch.float64, device="cuda")
+        p.exec(x, s, d_stats=st)                                                   # the good case
+        with pytest.raises(ValueError, match="elements"):
+            p.exec(x[:3], s, d_stats=st)
+        with pytest.raises(ValueError, match="dtype"):
+            p.exec(x.to(torch.complex128), s, d_stats=st)
+        with pytest.raises(ValueError, match="dtype"):
+            p.exec(x, s.double(), d_stats=st)
+        with pytest.raises(ValueError, match="contiguous"):
+            p.exec(x.t(), s, d_stats=st)
+        with pytest.raises(ValueError, match="device"):
+            p.exec(x.cpu(), s, d_stats=st)
+        with pytest.raises(ValueError, match="elements"):
+            p.exec(x, s, d_stats=st[:2])
+        torch.cuda.synchronize()

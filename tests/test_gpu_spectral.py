@@ -501,3 +501,23 @@ def test_device_peak_pipeline_matches_reference_steps(fa, dtype):
     with fa.Plan(64, batch=1, dtype=1) as p:
         with pytest.raises(ValueError):
             p.exec_host_lines(np.ones(64, complex), axis_dt=0.1, guard=1.0, want=2)
+
+
+def test_close_lines_fit_matches_the_tall_least_squares(fa):
+    """Lines 0.6 to 1.2 resolution cells apart (and guard_mult < 1): the weights come from the
+    k x k normal equations reduced on the device, the reference solves the tall N0 x k system.  In
+    this regime the Gram matrix is ill-conditioned (its condition number is the square of the
+    basis'); the estimator must still return the reference's lines and weights."""
+    n0, dt = 2000, 0.01
+    t = np.arange(n0) * dt
+    cell = 2 * np.pi / (t[-1] - t[0])
+    for sep in (1.2, 0.9, 0.6):
+        E_true = np.array([-2.0, -2.0 + sep * cell, 3.0, 3.0 + sep * cell])
+        p_true = np.array([0.4, 0.3, 0.2, 0.1])
+        f = (p_true[None, :] * np.exp(-1j * E_true[None, :] * t[:, None])).sum(axis=1)
+        kw = dict(n_levels=4, pad_factor=16, guard_mult=0.5, dc_guard=0.5, min_weight=1e-9)
+        E, p, _, _ = fa.fft_from_timeseries(f, t, **kw)
+        Eo, po, _, _ = so.fft_from_timeseries(f, t, **kw)
+        assert E.shape == Eo.shape, (sep, E, Eo)
+        np.testing.assert_allclose(E, Eo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p, po, rtol=0, atol=1e-7)
