@@ -591,6 +591,7 @@ struct Plan {
     int64_t pipe_slab = 0;        // signals per slab
     char* d_lines = nullptr;      // candidate lists, picked lines, line positions, Gram blocks, time grid (mfft_lines_host)
     char* h_lines = nullptr;      // pinned mirror of the small results in d_lines
+    char* h_spec = nullptr;       // pinned landing buffer of the spectra (mfft_lines_host, medium sizes)
     int lines_want = 0;
     int64_t* d_peaks = nullptr;   // {max, sum, centroid} | count | candidate indices (mfft_exec_host_peaks)
     int64_t* h_peaks = nullptr;   // pinned mirror of d_peaks
@@ -629,7 +630,7 @@ static void plan_free(Plan* p)
     for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
                     (void*)p->d_peaks, (void*)p->d_lines})
         if (q) (void)hipFree(q);
-    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines})
+    for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines, (void*)p->h_spec})
         if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1], p->last_done})
         if (e) (void)hipEventDestroy(e);
@@ -1518,6 +1519,7 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
         }
     }
     MFFT_HIP(hipMemcpyAsync(h_down, d + o_down, h_gram ? down_bytes : (o_gram - o_down), hipMemcpyDeviceToHost, nullptr));
+    bool pinned_spec = false;
     if (h_S) {
         if (normalize) {
             // S / (S.max() if S.max() > 0 else 1.0), per spectrum, in place on the device copy (final2.py:146)
@@ -1527,15 +1529,25 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
                 if (rc) return rc;
             }
         }
-        MFFT_HIP(hipMemcpyAsync(h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        // A download into a fresh pageable array runs at ~17 GB/s (one staging thread, page faults
+        // included); through a pinned landing buffer and the copy threads it is ~2x faster from 1 MiB on
+        pinned_spec = out_bytes >= (size_t(1) << 20) && out_bytes <= (size_t(256) << 20);
+        if (pinned_spec && !p->h_spec && hipHostMalloc((void**)&p->h_spec, out_bytes, hipHostMallocDefault) != hipSuccess) {
+            p->h_spec = nullptr;
+            pinned_spec = false;
+        }
+        MFFT_HIP(hipMemcpyAsync(pinned_spec ? (void*)p->h_spec : h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, nullptr));
     }
     MFFT_HIP(hipStreamSynchronize(nullptr));
+    uint64_t ticket = 0;
+    if (pinned_spec) ticket = CopyPool::out().start(h_S, p->h_spec, out_bytes);
     memcpy(h_stats, h_down + (o_stats - o_down), sizeof(double) * 3 * (size_t)B);
     memcpy(h_idx, h_down + (o_idx - o_down), sizeof(int64_t) * (size_t)(B * want));
     memcpy(h_omega_hat, h_down + (o_om - o_down), sizeof(double) * (size_t)(B * want));
     if (h_height) memcpy(h_height, h_down + (o_h - o_down), sizeof(double) * (size_t)(B * want));
     memcpy(h_count, h_down + (o_n - o_down), sizeof(int) * (size_t)B);
     if (h_gram) memcpy(h_gram, h_down + (o_gram - o_down), sizeof(double) * (size_t)B * nres);
+    if (pinned_spec) CopyPool::out().wait(ticket);
     return MFFT_OK;
 }
 

@@ -201,7 +201,8 @@ def fft_from_timeseries_batch(
 
     ``f_ts``: sequence of equally long signals, or an array of shape (B, N0).  Returns a list of
     B tuples ``(E_hat ascending, p, -omega, S_norm)``, each what the single-signal function
-    returns for that signal."""
+    returns for that signal.  The axis ``-omega`` is the same for every signal and is ONE array
+    shared by the tuples; the ``S_norm`` are rows of one (B, Nfft) array."""
     times = np.asarray(times, float)
     f_ts = [np.asarray(f) for f in f_ts]
     if times.ndim != 1 or times.size < 2:
@@ -232,11 +233,10 @@ def fft_from_timeseries_batch(
     res = plan.exec_host_lines(x, times, axis_dt=dt, guard=guard_mult * domega, want=want,
                                dc_guard=dc_guard * domega, include_dc=bool(include_dc), mode=0, scale=dt,
                                want_spectrum=True, want_fit=True, normalize=True)
-    omega = _omega_axis(nfft, dt)
+    E_axis = -_omega_axis(nfft, dt)                # one fresh array per call, shared by the batch's tuples
     out = []
     for b in range(B):
         S_norm = res["S"][b]                       # divided by its guarded maximum on the device
-        E_axis = -omega                            # a fresh array per signal, as the reference returns
         k = int(res["count"][b])
         if k == 0:
             out.append((np.array([]), np.array([]), E_axis, S_norm))
