@@ -1,14 +1,18 @@
 // Host-side exerciser of the C ABI for sanitizer builds (AddressSanitizer on host code only):
 //   make -C fft_amd/csrc VARIANT=asan KNOBS="-Xarch_host -fsanitize=address -g"
-//   g++ -std=c++17 -fsanitize=address -g tools/csrc/abi_smoke.cpp -Iinclude -Lfft_amd/lib -lmfft_asan \
-//       -Wl,-rpath,$PWD/fft_amd/lib -o tools/csrc/abi_smoke && tools/csrc/abi_smoke
+//   g++ -std=c++17 -fsanitize=address -g -D__HIP_PLATFORM_AMD__ tools/csrc/abi_smoke.cpp -Iinclude -I/opt/rocm/include \
+//       -Lfft_amd/lib -lmfft_asan -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,$PWD/fft_amd/lib -o tools/bin/abi_smoke
+//   ASAN_OPTIONS=detect_leaks=0 tools/bin/abi_smoke        (on the GPU box)
 // Walks every plan kind, the host entry points (small and pipelined transfers), the helper entry
 // points and the error paths; checks results loosely (parity is the Python tests' job).
 #include <complex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "mfft.h"
 
@@ -100,6 +104,95 @@ int main()
         REQUIRE(mfft_return_amplitude_host(f.data(), n, t.data(), 0.0, 0.0, w, c0, vrow, 2, 1.0) == MFFT_OK);
         REQUIRE(std::abs(f[0] - cd(1.0, 0.0)) < 1e-12);
         REQUIRE(mfft_return_amplitude_host(f.data(), n, nullptr, 0.0, 0.01, w, c0, vrow, 2, 1.0) == MFFT_OK);
+    }
+    // ---- line search of a batch (peak pipeline + fit on the device) ------------------------------------------
+    {
+        const int64_t n0 = 2000, n = 16 * n0, batch = 3;
+        const double dt = 0.01;
+        mfft_plan plan = nullptr;
+        REQUIRE(mfft_plan_1d(&plan, n, n0, batch, MFFT_C128, MFFT_HANN | MFFT_POWER | MFFT_STATS) == MFFT_OK);
+        std::vector<cd> x((size_t)(batch * n0));
+        std::vector<double> t((size_t)n0);
+        for (int64_t j = 0; j < n0; ++j) t[(size_t)j] = dt * (double)j;
+        for (int64_t b = 0; b < batch; ++b)
+            for (int64_t j = 0; j < n0; ++j)
+                x[(size_t)(b * n0 + j)] = 0.7 * std::polar(1.0, -(1.0 + (double)b) * t[(size_t)j]) + 0.3 * std::polar(1.0, 2.5 * t[(size_t)j]);
+        const double domega = 2 * M_PI / (t.back() - t.front());
+        mfft_peak_params prm{dt, 1.5 * domega, 1.2 * domega, 0, 0, 4};
+        const int want = prm.want;
+        std::vector<double> S((size_t)(batch * n)), stats(3 * batch), om((size_t)(batch * want)), hgt((size_t)(batch * want)),
+            gram((size_t)batch * (2 * want * want + 2 * want + 1));
+        std::vector<int64_t> idx((size_t)(batch * want));
+        std::vector<int32_t> cnt((size_t)batch);
+        for (int rep = 0; rep < 2; ++rep)
+            REQUIRE(mfft_lines_host(plan, x.data(), dt, 0.0, 0.0, dt, t.data(), &prm, 1, S.data(), stats.data(), idx.data(),
+                                    om.data(), hgt.data(), cnt.data(), gram.data()) == MFFT_OK);
+        for (int64_t b = 0; b < batch; ++b) {
+            REQUIRE(cnt[(size_t)b] >= 2);
+            REQUIRE(std::fabs(om[(size_t)(b * want)] + (1.0 + (double)b)) < 0.05);       // the tallest line: E = 1 + b, omega = -E
+        }
+        prm.want = 65;
+        REQUIRE(mfft_lines_host(plan, x.data(), dt, 0.0, 0.0, dt, t.data(), &prm, 0, nullptr, stats.data(), idx.data(), om.data(),
+                                nullptr, cnt.data(), nullptr) == MFFT_E_INVALID);
+        REQUIRE(mfft_plan_destroy(plan) == MFFT_OK);
+    }
+    // ---- the entry point that allocates nothing, on device arrays ------------------------------------------------
+    {
+        const int64_t n = 3000, batch = 2;
+        const int m = 5;
+        std::vector<cd> x((size_t)(batch * n), cd(1.0, 0.5));
+        std::vector<double> t((size_t)n), E((size_t)(batch * m), 0.3), out((size_t)batch * (2 * m * m + 2 * m + 1));
+        for (int64_t j = 0; j < n; ++j) t[(size_t)j] = 0.01 * (double)j;
+        void *d_x, *d_t, *d_E, *d_o;
+        REQUIRE(hipMalloc(&d_x, x.size() * sizeof(cd)) == hipSuccess && hipMalloc(&d_t, t.size() * 8) == hipSuccess &&
+                hipMalloc(&d_E, E.size() * 8) == hipSuccess && hipMalloc(&d_o, out.size() * 8) == hipSuccess);
+        REQUIRE(hipMemcpy(d_x, x.data(), x.size() * sizeof(cd), hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(hipMemcpy(d_t, t.data(), t.size() * 8, hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(hipMemcpy(d_E, E.data(), E.size() * 8, hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(mfft_lsq_normal_static(d_x, nullptr, (const double*)d_t, n, batch, nullptr, (const double*)d_E, m, (double*)d_o, nullptr) == MFFT_OK);
+        REQUIRE(hipMemcpy(out.data(), d_o, out.size() * 8, hipMemcpyDeviceToHost) == hipSuccess);
+        REQUIRE(std::fabs(out[0] - (double)n) < 1e-6 && std::fabs(out.back() - 1.25 * (double)n) < 1e-6);
+        REQUIRE(mfft_lsq_normal_static(d_x, nullptr, (const double*)d_t, n, 2000, nullptr, (const double*)d_E, 64, (double*)d_o, nullptr) == MFFT_E_UNSUPPORTED);
+        (void)hipFree(d_x); (void)hipFree(d_t); (void)hipFree(d_E); (void)hipFree(d_o);
+        int64_t fr = 0, tot = 0;
+        REQUIRE(mfft_device_memory(&fr, &tot) == MFFT_OK && fr > 0 && fr <= tot);
+    }
+    // ---- distributed plans: four ranks sharing the device, a host thread each -----------------------------------
+    {
+        const int P = 4;
+        const int64_t n0 = 256, n1 = 128;
+        mfft_comm comms[P];
+        REQUIRE(mfft_comm_init_local(comms, P) == MFFT_OK);
+        std::vector<int> rcs((size_t)P, -100);
+        std::vector<cf> result((size_t)(n0 * n1));
+        std::vector<std::thread> th;
+        for (int r = 0; r < P; ++r)
+            th.emplace_back([&, r] {
+                const int64_t local = n0 / P * n1;
+                std::vector<cf> mine((size_t)local, cf(1.0f, 0.0f));          // constant input: F[0][0] = n0*n1, zero elsewhere
+                void *d_in = nullptr, *d_out = nullptr;
+                mfft_dist_plan p2 = nullptr, p1 = nullptr;
+                int rc = hipMalloc(&d_in, (size_t)local * 8) == hipSuccess && hipMalloc(&d_out, (size_t)local * 8) == hipSuccess ? 0 : -99;
+                if (!rc) rc = hipMemcpy(d_in, mine.data(), (size_t)local * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -98;
+                if (!rc) rc = mfft_plan_2d_dist(&p2, comms[r], n0, n1, MFFT_C64, 1, 0);
+                if (!rc) rc = mfft_dist_exec(p2, d_in, d_out, nullptr);
+                if (!rc) rc = mfft_plan_1d_dist(&p1, comms[r], n0, n1, MFFT_C64, 1, 2);
+                if (!rc) rc = mfft_dist_exec(p1, d_in, d_out, nullptr);       // result overwritten below: exercised for its host side
+                if (!rc) rc = mfft_dist_exec(p2, d_in, d_out, nullptr);
+                if (!rc) rc = hipDeviceSynchronize() == hipSuccess ? 0 : -97;
+                if (!rc) rc = hipMemcpy(result.data() + (size_t)r * (size_t)local, d_out, (size_t)local * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -96;
+                (void)mfft_dist_plan_destroy(p2); (void)mfft_dist_plan_destroy(p1);
+                (void)hipFree(d_in); (void)hipFree(d_out);
+                rcs[(size_t)r] = rc;
+            });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < P; ++r) REQUIRE(rcs[(size_t)r] == MFFT_OK);
+        REQUIRE(std::fabs(result[0].real() - (float)(n0 * n1)) < 1e-2f && std::abs(result[1]) < 1e-2f && std::abs(result.back()) < 1e-2f);
+        int world = 0, rank = -1;
+        REQUIRE(mfft_comm_info(comms[2], &world, &rank) == MFFT_OK && world == P && rank == 2);
+        for (int r = 0; r < P; ++r) REQUIRE(mfft_comm_destroy(comms[r]) == MFFT_OK);
+        mfft_dist_plan bad = nullptr;
+        REQUIRE(mfft_plan_2d_dist(&bad, nullptr, 64, 64, MFFT_C64, 0, 0) == MFFT_E_INVALID);
     }
     // ---- error paths ---------------------------------------------------------------------------------------
     {
