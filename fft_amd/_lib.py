@@ -39,6 +39,7 @@ SIGNATURES = {
     "mfft_version": (_int, []),
     "mfft_device_count": (_int, []),
     "mfft_device_memory": (_int, [ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "mfft_release_cached": (_int, []),
     "mfft_strerror": (ctypes.c_char_p, [_int]),
     "mfft_last_error": (ctypes.c_char_p, []),
     "mfft_plan_1d": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32]),

@@ -950,6 +950,15 @@ struct DeviceGuard {
 // ===========================================================================
 using namespace mfft;
 
+// Device / pinned blocks that helper entry points keep between calls (released by mfft_release_cached)
+struct LsqScratch { double* dev = nullptr; double* pin = nullptr; size_t cap = 0; };
+static std::mutex g_lsq_mu;
+static LsqScratch g_lsq_pool[64];                       // mfft_lsq_normal_host: one per device
+struct TwiddleTable { int device = -1; int64_t n = 0; cx<double>* d = nullptr; int lo_bits = 0; uint64_t used = 0; };
+static std::mutex g_tab_mu;
+static TwiddleTable g_tabs[8];                          // mfft_twiddle_tile: most recent moduli
+static uint64_t g_tab_tick = 0;
+
 extern "C" {
 
 int mfft_version(void) { return 100; }
@@ -962,6 +971,34 @@ int mfft_device_count(void)
         return MFFT_E_NODEVICE;
     }
     return n;
+}
+
+int mfft_release_cached(void)
+{
+    int prev = 0;
+    const bool have = hipGetDevice(&prev) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_lsq_mu);
+        for (int dev = 0; dev < 64; ++dev) {
+            LsqScratch& sc = g_lsq_pool[dev];
+            if (!sc.dev && !sc.pin) continue;
+            (void)hipSetDevice(dev);
+            if (sc.dev) (void)hipFree(sc.dev);
+            if (sc.pin) (void)hipHostFree(sc.pin);
+            sc = LsqScratch{};
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_tab_mu);
+        for (TwiddleTable& t : g_tabs) {
+            if (!t.d) continue;
+            (void)hipSetDevice(t.device);
+            (void)hipFree(t.d);
+            t = TwiddleTable{};
+        }
+    }
+    if (have) (void)hipSetDevice(prev);
+    return MFFT_OK;
 }
 
 int mfft_device_memory(int64_t* free_bytes, int64_t* total_bytes)
@@ -1216,20 +1253,19 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
     for (int i = 0; i < 64; ++i) a.E[i] = i < m ? h_E[i] : 0.0;
     // One device block and one pinned host block per device, kept and grown as needed (a call takes
     // ~50 us; concurrent callers queue on the lock):  x (2n) | times (n) | win (n) | results (2mm + 2m + 1)
-    struct Scratch { double* dev = nullptr; double* pin = nullptr; size_t cap = 0; };
-    static std::mutex pool_mu;
-    static Scratch pool[64];
+    std::mutex& pool_mu = g_lsq_mu;
+    LsqScratch (&pool)[64] = g_lsq_pool;
     int device = 0;
     MFFT_HIP(hipGetDevice(&device));
     if (device < 0 || device >= 64) { set_error("device index out of range"); return MFFT_E_UNSUPPORTED; }
     const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
     const size_t doubles = 4 * (size_t)n + nres;
     std::lock_guard<std::mutex> lock(pool_mu);
-    Scratch& sc = pool[device];
+    LsqScratch& sc = pool[device];
     if (sc.cap < doubles) {
         if (sc.dev) (void)hipFree(sc.dev);
         if (sc.pin) (void)hipHostFree(sc.pin);
-        sc = Scratch{};
+        sc = LsqScratch{};
         const size_t want = doubles + doubles / 2;
         MFFT_HIP(hipMalloc((void**)&sc.dev, want * sizeof(double)));
         MFFT_HIP(hipHostMalloc((void**)&sc.pin, want * sizeof(double), hipHostMallocDefault));
@@ -1617,10 +1653,10 @@ int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t
     if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("bad dtype"); return MFFT_E_INVALID; }
     // Two-level table, k = hi * 2^lo_bits + lo, kept per (device, n_total): a job uses one or two
     // moduli, so the few most recent tables stay on the device and a call is one kernel launch.
-    struct Table { int device = -1; int64_t n = 0; cx<double>* d = nullptr; int lo_bits = 0; uint64_t used = 0; };
-    static std::mutex tab_mu;
-    static Table tabs[8];
-    static uint64_t tick = 0;
+    using Table = TwiddleTable;
+    std::mutex& tab_mu = g_tab_mu;
+    Table (&tabs)[8] = g_tabs;
+    uint64_t& tick = g_tab_tick;
     int device = 0;
     MFFT_HIP(hipGetDevice(&device));
     const cx<double>* d_tab = nullptr;

@@ -140,10 +140,12 @@ def _column_shape(shape, axis, n):
 
 
 def clear_plan_cache():
-    """Forget every cached plan; each frees its device memory once no caller holds it any more."""
+    """Forget every cached plan; each frees its device memory once no caller holds it any more.
+    Also releases the blocks the library's helper entry points keep between calls."""
     with _cache_lock:
         _cache.clear()
         _cache_bytes.clear()
+    _lib.load().mfft_release_cached()
 
 
 def engine_dtype(a: np.ndarray):

@@ -56,6 +56,8 @@ typedef struct mfft_plan_s* mfft_plan;
 int         mfft_version(void);            /* 10000*major + 100*minor + patch */
 int         mfft_device_count(void);       /* number of HIP devices, or MFFT_E_NODEVICE */
 int         mfft_device_memory(int64_t* free_bytes, int64_t* total_bytes);   /* of the current device (plan caches size themselves by it) */
+int         mfft_release_cached(void);     /* frees what helper entry points keep between calls: the staging block of
+                                              mfft_lsq_normal_host (per device) and the tables of mfft_twiddle_tile */
 const char* mfft_strerror(int code);
 const char* mfft_last_error(void);
 
