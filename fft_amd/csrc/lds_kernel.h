@@ -21,6 +21,7 @@
 // twiddles) are fetched once into registers and reused for every signal.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 // Tuning knobs (overridable with -D for A/B builds; the defaults are the measured best).
 #ifndef MFFT_TW_SRC
@@ -62,10 +63,20 @@
 #ifndef MFFT_R1024
 #define MFFT_R1024 16, 4, 16, 1
 #endif
+#ifndef MFFT_DMA
+#define MFFT_DMA 1           // the largest plain kernels fetch the next signal by LDS-DMA (dma_default): 0 = off, 1 = whole signal
+#endif                       // behind the last exchange, 2 = half of it during the butterflies (split exchanges) and half behind the last exchange
+#ifndef MFFT_DIAG_STAMPS
+#define MFFT_DIAG_STAMPS 0   // diagnostic builds only: per-workgroup cycle counts of the LDS-DMA pipeline's phases (mfft_diag_read)
+#endif
 
 namespace mfft {
 
-enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
+#if MFFT_DIAG_STAMPS
+__device__ unsigned long long g_diag_stamps[8 * 2048];
+#endif
+
+enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_LDSC = 3 };   // TW_LDSC: LDS table, large passes keep w^1 and w^4 only
 enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2, WIN_BUF = 3 };
 
 // Waves per SIMD the register allocator must leave room for (1 = no constraint).  In its
@@ -154,6 +165,30 @@ template <typename V, int AUX = 0> __device__ __forceinline__ void buf_st(__amdg
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
+// ---- pieces of the LDS-DMA pipeline (dma_default) -------------------------------------------
+// Workgroup barrier for LDS traffic alone: it waits for this wave's LDS operations and not for the
+// vector-memory counter, so global stores and LDS-DMA loads stay in flight across it
+// (__syncthreads() carries a fence that drains them).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// One wave-instruction of LDS-DMA: 64 lanes x 16 bytes, lane l from the wave-uniform address sbase
+// plus its own byte offset voff, into the 1 KiB of LDS that starts at the wave-uniform byte address
+// lds_dst.  No register destination; completion is counted on vmcnt like any load.  M0 holds the
+// destination and belongs to the compiler, hence saved and restored inside the statement.
+__device__ __forceinline__ void dma_1k(const void* sbase, uint32_t voff, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// wait until at most LEFT vector-memory operations of this wave are outstanding (they retire in issue order)
+template <int LEFT> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LEFT) : "memory");
+}
+
 template <int R0, int R1, int R2, int R3, bool SPLIT16 = (MFFT_TW16_SPLIT != 0)> struct Radices {
     static constexpr int r[4] = {R0, R1, R2, R3};
     static constexpr bool split16 = SPLIT16;   // radix-16 passes keep six twiddle generators (see tw_rows)
@@ -179,13 +214,45 @@ template <class RD> constexpr int tw_pass_offset(int s)
     return off;
 }
 
-template <int TX> __device__ __forceinline__ void exchange_sync()
+// Compact LDS table (TW_LDSC): a split radix-16 pass of NS >= kTwCompactFrom keeps only w^1 and w^4
+// per position and forms w^2 = (w^1)^2, w^3 = w^2 w^1, w^8 = (w^4)^2, w^12 = w^8 w^4 on the fly
+// (at most two roundings more than a table entry).
+constexpr int kTwCompactFrom = 1024;
+template <class RD> constexpr bool twc_compact(int s) { return RD::r[s] == 16 && RD::split16 && RD::ns(s) >= kTwCompactFrom; }
+template <class RD> constexpr int twc_rows(int s) { return twc_compact<RD>(s) ? 2 : tw_rows(RD::r[s], RD::split16); }
+template <class RD> constexpr int twc_pass_offset(int s)
+{
+    int off = 0;
+    for (int q = 1; q < s; ++q) off += twc_rows<RD>(q) * RD::ns(q);
+    return off;
+}
+template <class RD> constexpr int twc_total_elems()
+{
+    int c = 0;
+    for (int s = 1; s < RD::npass; ++s) c += twc_rows<RD>(s) * RD::ns(s);
+    return c;
+}
+template <typename T, class RD, int S, int BLOCK>
+__device__ __forceinline__ void fill_twc(cx<T>* twl, const cx<T>* __restrict__ tw)
+{
+    if constexpr (S < RD::npass) {
+        constexpr int NS = RD::ns(S), off = tw_pass_offset<RD>(S), offc = twc_pass_offset<RD>(S);
+        for (int i = threadIdx.x; i < twc_rows<RD>(S) * NS; i += BLOCK) {
+            const int r = i / NS, m = i % NS;
+            twl[offc + i] = tw[off + (twc_compact<RD>(S) ? 3 * r : r) * NS + m];     // compact: rows 0 and 3 (w^1, w^4)
+        }
+    }
+}
+
+template <int TX, bool RAW = false> __device__ __forceinline__ void exchange_sync()
 {
     if constexpr (TX <= 64) {
         // signal confined to one wave: only the compiler must not reorder
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if constexpr (RAW) {
+        lds_barrier();
     } else {
         __syncthreads();
     }
@@ -222,9 +289,18 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
         for (int u = 0; u < U; ++u) {
             const int m = (t + TX * u) % NS;
             cx<T> row[ROWS];
+            if constexpr (TWSRC == TW_LDSC && twc_compact<RD>(S)) {
+                constexpr int offc = twc_pass_offset<RD>(S);
+                static_assert(ROWS == 6, "compact tables serve split radix-16 passes");
+                const cx<T> w1 = twl[offc + m], w4 = twl[offc + NS + m];
+                row[0] = w1; row[1] = cmul(w1, w1); row[2] = cmul(row[1], w1);
+                row[3] = w4; row[4] = cmul(w4, w4); row[5] = cmul(row[4], w4);
+            } else
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-                if constexpr (TWSRC == TW_REG) {
+                if constexpr (TWSRC == TW_LDSC) {
+                    row[r] = twl[twc_pass_offset<RD>(S) + r * NS + m];
+                } else if constexpr (TWSRC == TW_REG) {
                     // register copy: one set per thread when m does not depend on u
                     row[r] = twr[twr_pos + ((NS <= TX) ? 0 : u * ROWS) + r];
                     if constexpr (ROWS != R - 1) {
@@ -261,11 +337,13 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
 
 // Scatter the pass outputs into LDS in Stockham order and gather the next
 // pass' inputs (positions t + TX*e).
-template <typename T, class RD, int S, int P, int TX, int PADSHIFT>
+template <typename T, class RD, int S, int P, int TX, int PADSHIFT, bool RAW = false>
 __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
-    if constexpr (TX > 64) __syncthreads();   // everyone has finished reading the previous contents
+    if constexpr (TX > 64) {                  // everyone has finished reading the previous contents
+        if constexpr (RAW) lds_barrier(); else __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int j = t + TX * u;
@@ -273,9 +351,40 @@ __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
 #pragma unroll
         for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q];
     }
-    exchange_sync<TX>();
+    exchange_sync<TX, RAW>();
 #pragma unroll
     for (int e = 0; e < P; ++e) v[e] = lds[lds_pad<PADSHIFT>(t + TX * e)];
+}
+
+// The same exchange with real and imaginary parts taken through LDS one after the other: half the
+// buffer (N scalars), twice the barriers.  The LDS-DMA pipeline uses it to free LDS for the signal
+// that is being fetched.  Entry: nobody still reads the buffer; exit: everybody has read it.
+template <typename T, class RD, int S, int P, int TX, int PADSHIFT>
+__device__ __forceinline__ void pass_exchange_split(cx<T> (&v)[P], int t, T* lds)
+{
+    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + TX * u;
+        const int base = (j / NS) * (NS * R) + (j % NS);
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q].x;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < P; ++e) v[e].x = lds[lds_pad<PADSHIFT>(t + TX * e)];      // .y still holds the old layout
+    lds_barrier();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + TX * u;
+        const int base = (j / NS) * (NS * R) + (j % NS);
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q].y;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < P; ++e) v[e].y = lds[lds_pad<PADSHIFT>(t + TX * e)];
+    lds_barrier();
 }
 
 // Copy the twiddles pass S needs for this thread into its register array.
@@ -344,6 +453,13 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 // +14 % Hann + power; 4096 points: the power-only and statistics variants (+6..7 %) but not the
 // windowed ones (-3..-6 %).  From 8192 points the extra registers spill (8192: 4.7 -> 4.0 TB/s,
 // 16384: 4.1 -> 2.4) and complex128 loses 1..17 % at every length.
+// Where the next signal is fetched by LDS-DMA (below, "LDS-DMA pipeline"): the plain kernels whose
+// one workgroup per CU leaves nothing else to overlap with.
+template <typename T, int N, int VAR> constexpr bool dma_default()
+{
+    return MFFT_DMA != 0 && sizeof(T) == 4 && N == 16384 && (VAR == V_PLAIN || VAR == V_SEG);
+}
+
 template <typename T, int N, int VAR> constexpr bool prefetch_default()
 {
     if (sizeof(T) != 4) return false;
@@ -352,7 +468,18 @@ template <typename T, int N, int VAR> constexpr bool prefetch_default()
     return false;
 }
 
-template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
+// LDS-DMA pipeline (DMA = true; one signal per workgroup, plain variants).  With one resident workgroup
+// per CU nothing overlaps a signal's load, butterfly and store phases, and neither registers nor LDS
+// hold a second signal.  Here the NEXT signal is fetched by LDS-DMA -- loads without a register
+// destination.  The exchanges take real and imaginary parts through LDS separately, which halves
+// their buffer and frees room for half a signal: that half is requested when the butterflies begin,
+// the other half into the exchange buffer as soon as the last exchange has been read out of it;
+// the last pass and the stores follow, and the wait at the end of the trip leaves exactly the P
+// stores outstanding, which drain during the next trip.  A CU streams from HBM only as fast as its
+// outstanding requests allow, so what counts is that requests are in flight during the butterflies.
+// Inside the loop every barrier is an LDS-only barrier and every twiddle comes from LDS, because a
+// compiler-counted global load or a __syncthreads() fence would wait for everything outstanding.
+template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR, bool DMA = false>
 __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
 {
     using C = cx<T>;
@@ -367,8 +494,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr bool FASTWIN = (VAR == V_HANN_POWER || VAR == V_WIN || VAR == V_HANN_POWER_STATS);   // window samples held per lane
     constexpr bool GENERAL = (VAR == V_GEN_CPLX || VAR == V_GEN_POWER);
     constexpr int TWN = twreg_count<RD, TX, P>();
-    constexpr int TWSRC = tw_source<T, RD, TX, P, VAR>();
+    constexpr int TWSRC = DMA ? TW_LDSC : tw_source<T, RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
+    static_assert(!DMA || (SLOTS == 1 && TX > 64 && (VAR == V_PLAIN || VAR == V_SEG) && NPASS >= 2),
+                  "the LDS-DMA pipeline serves plain signals that own their workgroup");
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
     // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
     // offsets instead, 2.4 -> 3.5 TB/s; with 16 points per thread at 8192 the register copy is 5-7 % faster
@@ -381,12 +510,28 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     const int slot = threadIdx.x / TX;
     const int t = threadIdx.x % TX;
     C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
+    // LDS-DMA pipeline: [exchange buffer of LDS_ELEMS scalars, which also receives the second half of the
+    // next signal] [first half of the next signal] [twiddle tables]
+    constexpr bool SPLIT = DMA && MFFT_DMA == 2;
+    constexpr int DMA_EX_BYTES = SPLIT ? (LDS_ELEMS * (int)sizeof(T) + 1023) / 1024 * 1024 : LDS_ELEMS * (int)sizeof(C);
+    constexpr int DMA_HALF_BYTES = N * (int)sizeof(C) / 2;
+    constexpr int DMA_FIRST_AT = SPLIT ? DMA_EX_BYTES : 0;                      // byte offset of the first half's image
+    constexpr int DMA_SECOND_AT = SPLIT ? 0 : DMA_HALF_BYTES;
+    constexpr int DMA_TABLES_AT = SPLIT ? DMA_EX_BYTES + DMA_HALF_BYTES : DMA_EX_BYTES;
+    static_assert(!DMA || DMA_HALF_BYTES <= DMA_EX_BYTES, "the exchange buffer receives half a signal");
 
     // ---- tables shared by the workgroup, staged in LDS behind the data slots --
-    C* twl = reinterpret_cast<C*>(smem_raw) + (size_t)SLOTS * LDS_ELEMS;
+    C* twl = DMA ? reinterpret_cast<C*>(smem_raw + DMA_TABLES_AT)
+                 : reinterpret_cast<C*>(smem_raw) + (size_t)SLOTS * LDS_ELEMS;
     T* winl = reinterpret_cast<T*>(twl + (TWSRC == TW_LDS ? tw_total_elems<RD>() : 0));
     if constexpr (TWSRC == TW_LDS) {
         for (int i = threadIdx.x; i < tw_total_elems<RD>(); i += BLOCK) twl[i] = a.tw[i];
+    }
+    if constexpr (TWSRC == TW_LDSC) {
+        fill_twc<T, RD, 1, BLOCK>(twl, a.tw);
+        fill_twc<T, RD, 2, BLOCK>(twl, a.tw);
+        fill_twc<T, RD, 3, BLOCK>(twl, a.tw);
+        __syncthreads();
     }
     if constexpr (FASTWIN && WINSRC == WIN_LDS) {
         for (int i = threadIdx.x; i < N; i += BLOCK) winl[i] = a.win[i];
@@ -446,13 +591,73 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     if constexpr (PREFETCH) {
         if ((int64_t)blockIdx.x < groups) load_fast(vn, (int64_t)blockIdx.x * SLOTS + slot);
     }
+    // LDS-DMA of half a signal as a lane-linear image (element j at byte j * sizeof(C) of its half).
+    // A piece is one wave-instruction = 1 KiB = PE consecutive elements, which lie inside one row of
+    // TX elements, hence inside one segment; wave w moves pieces w, w + NW, ... : the first PPW / 2
+    // of them make up the first half.
+    constexpr int PE = 1024 / (int)sizeof(C), NW = BLOCK / 64;
+    constexpr int PPW = DMA ? (N / PE) / NW : 2;
+    static_assert(!DMA || (PPW % 2 == 0 && (PPW / 2) * NW * PE == N / 2), "halves are whole pieces per wave");
+    const uint32_t stage_lds = (uint32_t)reinterpret_cast<size_t>(smem_raw);       // LDS byte address of the exchange buffer
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const auto dma_half = [&](int64_t bsig, auto half) {
+        const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;      // wave-uniform
+        const uint32_t lane_off = (threadIdx.x & 63u) * 16u;
+        const int q = a.in_lseg - LOG2TX;
+        constexpr int H = decltype(half)::value;
+#pragma unroll
+        for (int i = H * (PPW / 2); i < (H + 1) * (PPW / 2); ++i) {
+            const int piece = wv + NW * i;
+            const int j0 = piece * PE;
+            int64_t off = j0;
+            if constexpr (VAR == V_SEG) {
+                const int e = j0 >> LOG2TX;
+                off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
+            }
+            // first half behind the exchange buffer, second half in it
+            dma_1k(src + off, lane_off, stage_lds + (uint32_t)(H == 0 ? DMA_FIRST_AT : DMA_SECOND_AT - DMA_HALF_BYTES) + (uint32_t)piece * 1024u);
+        }
+    };
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+#if MFFT_DIAG_STAMPS
+    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#define MFFT_STAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now__ - stamp_prev; stamp_prev = now__; } while (0)
+#else
+#define MFFT_STAMP(k) do { } while (0)
+#endif
+    if constexpr (DMA) {
+        if ((int64_t)blockIdx.x < groups) {
+            dma_half((int64_t)blockIdx.x, Half0{});
+            dma_half((int64_t)blockIdx.x, Half1{});
+        }
+        wait_vm<0>();
+        lds_barrier();
+    }
     for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
         const int64_t b = g * SLOTS + slot;
         const bool active = b < a.batch;
         C v[P];
+        // LDS-DMA pipeline: every address of a trip is derived from tl inside the trip.  Hoisted out of
+        // the loop, the scatter addresses of the exchanges do not fit the 128 registers of a 1024-thread
+        // workgroup, and a reload from scratch is a counted vector-memory load: it would wait for the
+        // stores and the DMA in flight.
+        int tl = t;
+        if constexpr (DMA) asm volatile("" : "+v"(tl));
 
         // ---- load ----------------------------------------------------------------
-        if constexpr (!GENERAL) {
+        if constexpr (DMA) {
+            const C* first = reinterpret_cast<const C*>(smem_raw + DMA_FIRST_AT);
+            const C* second = reinterpret_cast<const C*>(smem_raw + DMA_SECOND_AT);
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = e < P / 2 ? first[tl + TX * e] : second[tl + TX * (e - P / 2)];
+            lds_barrier();                                  // both halves are in registers everywhere
+            if constexpr (SPLIT) {
+                if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
+            }
+            MFFT_STAMP(0);
+        } else if constexpr (!GENERAL) {
             if constexpr (PREFETCH) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = vn[e];
@@ -554,19 +759,42 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 
         // ---- passes ---------------------------------------------------------
 #if !MFFT_DIAG_NOFFT
-        pass_compute<T, RD, 0, P, TX, TWSRC>(v, t, a.tw, twr, twl);
+        // the exchange buffer is idle from the last exchange on: the second half of the next signal goes there
+        const auto dma_rest = [&]() {
+            if constexpr (!SPLIT) {
+                lds_barrier();                              // every wave has read its exchange results
+                if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
+            }
+            if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half1{});
+            MFFT_STAMP(1);
+        };
+        const auto exchange = [&](auto pass) {
+            constexpr int S = decltype(pass)::value;
+            if constexpr (SPLIT) {
+                pass_exchange_split<T, RD, S, P, TX, PADSHIFT>(v, tl, reinterpret_cast<T*>(smem_raw));
+                if constexpr (S == NPASS - 2) dma_rest();
+            } else if constexpr (DMA) {
+                pass_exchange<T, RD, S, P, TX, PADSHIFT, true>(v, tl, lds);
+                if constexpr (S == NPASS - 2) dma_rest();
+            } else {
+                pass_exchange<T, RD, S, P, TX, PADSHIFT>(v, tl, lds);
+            }
+        };
+        pass_compute<T, RD, 0, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
         if constexpr (NPASS > 1) {
-            pass_exchange<T, RD, 0, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 1, P, TX, TWSRC>(v, t, a.tw, twr, twl);
+            exchange(std::integral_constant<int, 0>{});
+            pass_compute<T, RD, 1, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
         }
         if constexpr (NPASS > 2) {
-            pass_exchange<T, RD, 1, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 2, P, TX, TWSRC>(v, t, a.tw, twr, twl);
+            exchange(std::integral_constant<int, 1>{});
+            pass_compute<T, RD, 2, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
         }
         if constexpr (NPASS > 3) {
-            pass_exchange<T, RD, 2, P, TX, PADSHIFT>(v, t, lds);
-            pass_compute<T, RD, 3, P, TX, TWSRC>(v, t, a.tw, twr, twl);
+            exchange(std::integral_constant<int, 2>{});
+            pass_compute<T, RD, 3, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
         }
+#else
+        if constexpr (DMA) dma_rest();
 #endif
 
         // ---- store: output k = t + TX*e sits in v[e] --------------------------
@@ -687,15 +915,30 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #pragma unroll
                     for (int e = 0; e < P; ++e) {
                         const int64_t off = (int64_t)(e >> q) * a.out_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
-                        st_stream(dst + off + t, v[e]);
+                        st_stream(dst + off + tl, v[e]);
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < P; ++e) st_stream(dst + t + TX * e, v[e]);
+                    for (int e = 0; e < P; ++e) st_stream(dst + tl + TX * e, v[e]);
                 }
             }
         }
+        if constexpr (DMA) {
+            // The next signal has landed once everything issued before this trip's P stores has
+            // retired (one store instruction per point held; `active` is always true here).
+            MFFT_STAMP(2);
+            wait_vm<P>();
+            lds_barrier();
+            MFFT_STAMP(3);
+        }
     }
+#if MFFT_DIAG_STAMPS
+    if constexpr (DMA) {
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {
+            for (int k = 0; k < 4; ++k) g_diag_stamps[blockIdx.x * 8 + k] = stamp_acc[k];
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -777,14 +1020,33 @@ template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_f
 int blocks_per_cu(const void* kernel, int block, size_t lds);
 int pick_grid(int per_cu, int64_t groups);
 
-template <typename T, int LOG2N, int VAR>
+// The LDS-DMA pipeline moves 16 bytes per lane: signals (and segments) must start on 16-byte boundaries.
+// MFFT_NO_DMA=1 in the environment selects the register-load form (A/B timing, tests).
+template <typename T, int VAR> bool dma_usable(const KArgs<T>& a)
+{
+    const size_t es = sizeof(cx<T>);
+    if ((reinterpret_cast<size_t>(a.in) & 15) || ((size_t)a.in_stride * es & 15)) return false;
+    if (VAR == V_SEG && ((size_t)a.in_seg_stride * es & 15)) return false;
+    const char* off = getenv("MFFT_NO_DMA");
+    return !(off && off[0] == '1');
+}
+
+template <typename T, int LOG2N, int VAR, bool DMA = false>
 int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
 {
     using SC = SizeFor<T, LOG2N>;
     constexpr int BLOCK = BlockCfg<T, LOG2N, VAR>::BLOCK;
     constexpr int SLOTS = BLOCK / BlockCfg<T, LOG2N, VAR>::TX;
-    constexpr size_t lds = (SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0;
-    auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
+    if constexpr (!DMA && dma_default<T, (1 << LOG2N), VAR>()) {
+        if (dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
+    }
+    constexpr int LDS_ELEMS = ((lds_pad<kPadShift>((1 << LOG2N) - 1) + 1 + 1) / 2) * 2;
+    constexpr size_t lds = DMA ? (MFFT_DMA == 2 ? ((size_t)LDS_ELEMS * sizeof(T) + 1023) / 1024 * 1024 + ((size_t)sizeof(cx<T>) << LOG2N) / 2
+                                                : (size_t)LDS_ELEMS * sizeof(cx<T>)) +
+                                     twc_total_elems<typename SC::RD>() * sizeof(cx<T>)
+                               : ((SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0);
+    static_assert(lds <= 160 * 1024, "LDS of one workgroup");
+    auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR, DMA>;
     static thread_local int attr_dev = -1, per_cu = 1;
     int dev = 0;
     MFFT_HIP(hipGetDevice(&dev));

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""LDS-DMA pipeline against the register-load form of the same kernels (MFFT_NO_DMA=1), one process,
+interleaved rounds: parity against a float64 transform, then microseconds per launch.
+    python tools/dma_ab.py [--points 26]"""
+import argparse, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fft_amd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=26)
+ap.add_argument("--sizes", default="14:0 13:0 13:1")
+ap.add_argument("--lib", default="", help="variant library, e.g. fft_amd/lib/libmfft_nofft.so (diagnostic builds: errors are meaningless)")
+a = ap.parse_args()
+if a.lib:
+    fft_amd._lib.LIB_PATH = os.path.abspath(a.lib)
+torch.cuda.set_device(0)
+stream = torch.cuda.current_stream().cuda_stream
+warm = torch.randn(1 << 24, device="cuda")
+for _ in range(3000): warm.mul_(1.0001)
+for item in a.sizes.split():
+    k, dtype = map(int, item.split(":"))
+    n = 1 << k
+    batch = (1 << a.points) >> k
+    rdt, cdt = (torch.float32, torch.complex64) if dtype == 0 else (torch.float64, torch.complex128)
+    bufs = [(torch.view_as_complex(torch.randn((batch, n, 2), dtype=rdt, device="cuda")),
+             torch.empty((batch, n), dtype=cdt, device="cuda")) for _ in range(3)]       # > Infinity Cache in total
+    x, y = bufs[0]
+    res = {}
+    with fft_amd.Plan(n, batch=batch, dtype=dtype) as p:
+        for tag, env in (("dma", None), ("regs", "1")):
+            if env: os.environ["MFFT_NO_DMA"] = env
+            else: os.environ.pop("MFFT_NO_DMA", None)
+            y.zero_(); p.exec(x, y, stream=stream); torch.cuda.synchronize()
+            rows = [0, 1, batch // 2, batch - 1] + list(range(7, batch, max(1, batch // 23)))
+            err = 0.0
+            for r in rows:
+                ref = torch.fft.fft(x[r].to(torch.complex128))
+                err = max(err, (torch.linalg.vector_norm(y[r].to(torch.complex128) - ref) / torch.linalg.vector_norm(ref)).item())
+            res[tag] = [err, 1e9]
+        for rnd in range(6):
+            for tag, env in (("dma", None), ("regs", "1")):
+                if env: os.environ["MFFT_NO_DMA"] = env
+                else: os.environ.pop("MFFT_NO_DMA", None)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for i in range(3): p.exec(*bufs[i % 3], stream=stream)
+                e0.record()
+                for i in range(12): p.exec(*bufs[i % 3], stream=stream)
+                e1.record(); e1.synchronize()
+                res[tag][1] = min(res[tag][1], e0.elapsed_time(e1) / 12 * 1e3)
+    os.environ.pop("MFFT_NO_DMA", None)
+    lib = fft_amd._lib.load()
+    if hasattr(lib, "mfft_diag_read"):             # diagnostic build: phase ticks of the last DMA launch
+        import ctypes, numpy as np
+        with fft_amd.Plan(n, batch=batch, dtype=dtype) as p:
+            p.exec(x, y, stream=stream); torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * (8 * 256))()
+        lib.mfft_diag_read(buf, 8 * 256)
+        st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8)[:, :4].astype(float)
+        trips = batch / 256
+        print("   phase ticks per trip (100 MHz: x10 ns), mean over workgroups: read+issue %.0f | passes %.0f | last pass+stores %.0f | wait %.0f"
+              % tuple(st.mean(0) / trips), " total %.0f" % (st.sum(1).mean() / trips))
+    bytes_ = 2 * batch * n * (8 if dtype == 0 else 16)
+    print(f"2^{k} x {batch} {'c64' if dtype == 0 else 'c128'}: " + " | ".join(
+        f"{t}: {v[1]:7.1f} us {bytes_ / v[1] / 1e3:6.0f} GB/s err {v[0]:.1e}" for t, v in res.items()), flush=True)
+    del bufs, x, y
