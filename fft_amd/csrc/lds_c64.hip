@@ -45,7 +45,7 @@ bool lds_geometry(int dtype, int log2n, LdsGeometry* g)
 }  // namespace mfft
 
 #if MFFT_DIAG_STAMPS
-// diagnostic builds only: the phase cycle counts the last LDS-DMA launch left behind (8 per workgroup)
+// diagnostic builds only: the phase cycle counts the last LDS-DMA launch left behind (16 per workgroup)
 extern "C" int mfft_diag_read(unsigned long long* out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mfft::g_diag_stamps), sizeof(unsigned long long) * (size_t)n);

@@ -66,6 +66,12 @@
 #ifndef MFFT_DMA
 #define MFFT_DMA 1           // the largest plain kernels fetch the next signal by LDS-DMA (dma_default): 0 = off, 1 = whole signal
 #endif                       // behind the last exchange, 2 = half of it during the butterflies (split exchanges) and half behind the last exchange
+#ifndef MFFT_VEC
+#define MFFT_VEC -1          // packed-form butterflies (fft_core.h): -1 = where measured faster (vec_default), 0 = never, 1 = every complex64 kernel
+#endif
+#ifndef MFFT_DIAG_SKIP
+#define MFFT_DIAG_SKIP 0     // diagnostic builds only: bit 0 = no butterflies / twiddles, bit 1 = no LDS exchanges (results are wrong)
+#endif
 #ifndef MFFT_DIAG_STAMPS
 #define MFFT_DIAG_STAMPS 0   // diagnostic builds only: per-workgroup cycle counts of the LDS-DMA pipeline's phases (mfft_diag_read)
 #endif
@@ -73,7 +79,7 @@
 namespace mfft {
 
 #if MFFT_DIAG_STAMPS
-__device__ unsigned long long g_diag_stamps[8 * 2048];
+__device__ unsigned long long g_diag_stamps[16 * 2048];
 #endif
 
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_LDSC = 3 };   // TW_LDSC: LDS table, large passes keep w^1 and w^4 only
@@ -151,6 +157,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), (int)kBufWord3);
 }
+// the same for a base the compiler can see is uniform (kernel arguments and block indices only)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, (int)kBufWord3);
+}
 // AUX: cache-policy bits of the instruction (0 = default, 2 = streaming / non-temporal)
 template <typename V, int AUX = 0> __device__ __forceinline__ V buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
@@ -217,7 +228,7 @@ template <class RD> constexpr int tw_pass_offset(int s)
 // Compact LDS table (TW_LDSC): a split radix-16 pass of NS >= kTwCompactFrom keeps only w^1 and w^4
 // per position and forms w^2 = (w^1)^2, w^3 = w^2 w^1, w^8 = (w^4)^2, w^12 = w^8 w^4 on the fly
 // (at most two roundings more than a table entry).
-constexpr int kTwCompactFrom = 1024;
+constexpr int kTwCompactFrom = 512;
 template <class RD> constexpr bool twc_compact(int s) { return RD::r[s] == 16 && RD::split16 && RD::ns(s) >= kTwCompactFrom; }
 template <class RD> constexpr int twc_rows(int s) { return twc_compact<RD>(s) ? 2 : tw_rows(RD::r[s], RD::split16); }
 template <class RD> constexpr int twc_pass_offset(int s)
@@ -276,12 +287,13 @@ template <class RD, int TX, int P> constexpr int twreg_pass_offset(int s)
 
 // One Stockham pass on the registers of one thread; leaves v[u + U*q] = output q
 // of butterfly u.
-template <typename T, class RD, int S, int P, int TX, int TWSRC>
+template <typename T, class RD, int S, int P, int TX, int TWSRC, bool VEC = false>
 __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* __restrict__ tw,
                                              const cx<T>* twr, const cx<T>* twl)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
     constexpr int twr_pos = twreg_pass_offset<RD, TX, P>(S);
+    if constexpr ((MFFT_DIAG_SKIP & 1) != 0) return;
     if constexpr (S > 0) {
         constexpr int off = tw_pass_offset<RD>(S);
         constexpr int ROWS = tw_rows(R, RD::split16);
@@ -293,8 +305,8 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
                 constexpr int offc = twc_pass_offset<RD>(S);
                 static_assert(ROWS == 6, "compact tables serve split radix-16 passes");
                 const cx<T> w1 = twl[offc + m], w4 = twl[offc + NS + m];
-                row[0] = w1; row[1] = cmul(w1, w1); row[2] = cmul(row[1], w1);
-                row[3] = w4; row[4] = cmul(w4, w4); row[5] = cmul(row[4], w4);
+                row[0] = w1; row[1] = cmul<T, VEC>(w1, w1); row[2] = cmul<T, VEC>(row[1], w1);
+                row[3] = w4; row[4] = cmul<T, VEC>(w4, w4); row[5] = cmul<T, VEC>(row[4], w4);
             } else
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
@@ -316,7 +328,7 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
             }
             if constexpr (ROWS == R - 1) {
 #pragma unroll
-                for (int i = 1; i < R; ++i) v[u + U * i] = cmul(v[u + U * i], row[i - 1]);
+                for (int i = 1; i < R; ++i) v[u + U * i] = cmul<T, VEC>(v[u + U * i], row[i - 1]);
             } else {
                 // rows: w^1, w^2, w^3, w^4, w^8, w^12 (, .. w^28 for radix 32)
 #pragma unroll
@@ -325,22 +337,29 @@ __device__ __forceinline__ void pass_compute(cx<T> (&v)[P], int t, const cx<T>* 
                     cx<T> w;
                     if (b == 0) w = row[2 + a4];                      // w^4, w^8, w^12
                     else if (a4 == 0) w = row[b - 1];                 // w^1, w^2, w^3
-                    else w = cmul(row[2 + a4], row[b - 1]);
-                    v[u + U * i] = cmul(v[u + U * i], w);
+                    else w = cmul<T, VEC>(row[2 + a4], row[b - 1]);
+                    v[u + U * i] = cmul<T, VEC>(v[u + U * i], w);
                 }
             }
         }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) dft_strided<T, R, U>(&v[u]);
+    for (int u = 0; u < U; ++u) dft_strided<T, R, U, VEC>(&v[u]);
 }
 
 // Scatter the pass outputs into LDS in Stockham order and gather the next
 // pass' inputs (positions t + TX*e).
+// Padded LDS position of base + c for a compile-time c.  Positions of one exchange differ from a
+// per-thread base by multiples of NS (writes) or TX (reads); base mod 16 is below min(NS, 16) and
+// the low four bits of such a multiple leave room for it, so no carry crosses bit 4 and
+// pad(base + c) = pad(base) + pad(c): one address register per butterfly, immediate offsets for the rest.
+template <int SHIFT> MFFT_HD int lds_pad_off(int c) { return lds_pad<SHIFT>(c); }
+
 template <typename T, class RD, int S, int P, int TX, int PADSHIFT, bool RAW = false>
 __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    if constexpr ((MFFT_DIAG_SKIP & 2) != 0) return;
     if constexpr (TX > 64) {                  // everyone has finished reading the previous contents
         if constexpr (RAW) lds_barrier(); else __syncthreads();
     }
@@ -348,12 +367,24 @@ __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
     for (int u = 0; u < U; ++u) {
         const int j = t + TX * u;
         const int base = (j / NS) * (NS * R) + (j % NS);
+        if constexpr (RAW) {
+            cx<T>* w = lds + lds_pad<PADSHIFT>(base);
 #pragma unroll
-        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q];
+            for (int q = 0; q < R; ++q) w[lds_pad_off<PADSHIFT>(q * NS)] = v[u + U * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q];
+        }
     }
     exchange_sync<TX, RAW>();
+    if constexpr (RAW) {
+        const cx<T>* r = lds + lds_pad<PADSHIFT>(t);
 #pragma unroll
-    for (int e = 0; e < P; ++e) v[e] = lds[lds_pad<PADSHIFT>(t + TX * e)];
+        for (int e = 0; e < P; ++e) v[e] = r[lds_pad_off<PADSHIFT>(TX * e)];
+    } else {
+#pragma unroll
+        for (int e = 0; e < P; ++e) v[e] = lds[lds_pad<PADSHIFT>(t + TX * e)];
+    }
 }
 
 // The same exchange with real and imaginary parts taken through LDS one after the other: half the
@@ -457,7 +488,22 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 // one workgroup per CU leaves nothing else to overlap with.
 template <typename T, int N, int VAR> constexpr bool dma_default()
 {
-    return MFFT_DMA != 0 && sizeof(T) == 4 && N == 16384 && (VAR == V_PLAIN || VAR == V_SEG);
+    // complex128 at 8192 points measured 8 % slower this way (473 against 438 us per 2^26 points)
+    return MFFT_DMA != 0 && sizeof(T) == 4 && (N == 16384 || N == 8192) && (VAR == V_PLAIN || VAR == V_SEG);
+}
+
+// Where the packed-form butterflies measured faster (MI355X, complex64, 2^26 points per launch):
+// 2048 and 4096 points +2 % plain, +5..6 % Hann + power (but the 4096-point windowed, complex-output
+// variant -4 %: excluded); 8192 points power-only +9 % and the LDS-DMA kernels; every 16384-point
+// variant +10..19 %.  Within +-1.5 % at 256..1024 points and in the other 8192-point forms, which
+// keep the scalar form.
+template <typename T, int N, int VAR, bool DMA> constexpr bool vec_default()
+{
+    if (sizeof(T) != 4) return false;
+    if (MFFT_VEC >= 0) return MFFT_VEC != 0;
+    if (N == 4096) return VAR != V_WIN;
+    if (N == 8192) return DMA || VAR == V_POW || VAR == V_POW_STATS;
+    return DMA || N == 2048 || N == 16384;
 }
 
 template <typename T, int N, int VAR> constexpr bool prefetch_default()
@@ -496,6 +542,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int TWN = twreg_count<RD, TX, P>();
     constexpr int TWSRC = DMA ? TW_LDSC : tw_source<T, RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
+    constexpr bool VEC = vec_default<T, N, VAR, DMA>();
     static_assert(!DMA || (SLOTS == 1 && TX > 64 && (VAR == V_PLAIN || VAR == V_SEG) && NPASS >= 2),
                   "the LDS-DMA pipeline serves plain signals that own their workgroup");
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
@@ -621,7 +668,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     using Half0 = std::integral_constant<int, 0>;
     using Half1 = std::integral_constant<int, 1>;
 #if MFFT_DIAG_STAMPS
-    unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+    unsigned long long stamp_acc[16] = {};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #define MFFT_STAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now__ - stamp_prev; stamp_prev = now__; } while (0)
 #else
@@ -766,7 +813,6 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
             }
             if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half1{});
-            MFFT_STAMP(1);
         };
         const auto exchange = [&](auto pass) {
             constexpr int S = decltype(pass)::value;
@@ -780,18 +826,25 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 pass_exchange<T, RD, S, P, TX, PADSHIFT>(v, tl, lds);
             }
         };
-        pass_compute<T, RD, 0, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
+        pass_compute<T, RD, 0, P, TX, TWSRC, VEC>(v, tl, a.tw, twr, twl);
+        MFFT_STAMP(1);
         if constexpr (NPASS > 1) {
             exchange(std::integral_constant<int, 0>{});
-            pass_compute<T, RD, 1, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(2);
+            pass_compute<T, RD, 1, P, TX, TWSRC, VEC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(3);
         }
         if constexpr (NPASS > 2) {
             exchange(std::integral_constant<int, 1>{});
-            pass_compute<T, RD, 2, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(4);
+            pass_compute<T, RD, 2, P, TX, TWSRC, VEC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(5);
         }
         if constexpr (NPASS > 3) {
             exchange(std::integral_constant<int, 2>{});
-            pass_compute<T, RD, 3, P, TX, TWSRC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(6);
+            pass_compute<T, RD, 3, P, TX, TWSRC, VEC>(v, tl, a.tw, twr, twl);
+            MFFT_STAMP(7);
         }
 #else
         if constexpr (DMA) dma_rest();
@@ -910,6 +963,22 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     for (int e = 0; e < P; ++e) {
                         if (t + TX * e < a.n_out) dst[t + TX * e] = v[e];
                     }
+                } else if constexpr (DMA) {
+                    // buffer stores: base and row offset live in scalar registers, one lane-dependent
+                    // offset register serves all P stores and no vector instruction is spent on addresses
+                    const uint32_t voff = (uint32_t)tl * (uint32_t)sizeof(C);
+                    if constexpr (VAR == V_SEG) {
+                        const int q = a.out_lseg - LOG2TX;
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            const int64_t off = (int64_t)(e >> q) * a.out_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
+                            buf_st<C, MFFT_NT ? 2 : 0>(make_rsrc_uniform(dst + off, (uint32_t)TX * sizeof(C)), voff, 0u, v[e]);
+                        }
+                    } else {
+                        const auto ro = make_rsrc_uniform(dst, (uint32_t)N * sizeof(C));
+#pragma unroll
+                        for (int e = 0; e < P; ++e) buf_st<C, MFFT_NT ? 2 : 0>(ro, voff, TX * e * sizeof(C), v[e]);
+                    }
                 } else if constexpr (VAR == V_SEG) {
                     const int q = a.out_lseg - LOG2TX;
 #pragma unroll
@@ -926,16 +995,16 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         if constexpr (DMA) {
             // The next signal has landed once everything issued before this trip's P stores has
             // retired (one store instruction per point held; `active` is always true here).
-            MFFT_STAMP(2);
+            MFFT_STAMP(8);
             wait_vm<P>();
             lds_barrier();
-            MFFT_STAMP(3);
+            MFFT_STAMP(9);
         }
     }
 #if MFFT_DIAG_STAMPS
     if constexpr (DMA) {
         if (threadIdx.x == 0 && blockIdx.x < 2048) {
-            for (int k = 0; k < 4; ++k) g_diag_stamps[blockIdx.x * 8 + k] = stamp_acc[k];
+            for (int k = 0; k < 16; ++k) g_diag_stamps[blockIdx.x * 16 + k] = stamp_acc[k];
         }
     }
 #endif

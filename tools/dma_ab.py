@@ -55,12 +55,13 @@ for item in a.sizes.split():
         import ctypes, numpy as np
         with fft_amd.Plan(n, batch=batch, dtype=dtype) as p:
             p.exec(x, y, stream=stream); torch.cuda.synchronize()
-        buf = (ctypes.c_ulonglong * (8 * 256))()
-        lib.mfft_diag_read(buf, 8 * 256)
-        st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8)[:, :4].astype(float)
+        buf = (ctypes.c_ulonglong * (16 * 256))()
+        lib.mfft_diag_read(buf, 16 * 256)
+        st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16)[:, :10].astype(float)
         trips = batch / 256
-        print("   phase ticks per trip (100 MHz: x10 ns), mean over workgroups: read+issue %.0f | passes %.0f | last pass+stores %.0f | wait %.0f"
-              % tuple(st.mean(0) / trips), " total %.0f" % (st.sum(1).mean() / trips))
+        names = ["read", "pass0", "exch0", "pass1", "exch1", "pass2", "exch2+dma", "pass3", "scale+stores", "wait"]
+        print("   shader-clock ticks per trip, mean over workgroups: " + " | ".join(
+            f"{nm} {v:.0f}" for nm, v in zip(names, st.mean(0) / trips)) + f" | total {st.sum(1).mean() / trips:.0f}")
     bytes_ = 2 * batch * n * (8 if dtype == 0 else 16)
     print(f"2^{k} x {batch} {'c64' if dtype == 0 else 'c128'}: " + " | ".join(
         f"{t}: {v[1]:7.1f} us {bytes_ / v[1] / 1e3:6.0f} GB/s err {v[0]:.1e}" for t, v in res.items()), flush=True)
