@@ -489,7 +489,8 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 template <typename T, int N, int VAR> constexpr bool dma_default()
 {
     // complex128 at 8192 points measured 8 % slower this way (473 against 438 us per 2^26 points)
-    return MFFT_DMA != 0 && sizeof(T) == 4 && (N == 16384 || N == 8192) && (VAR == V_PLAIN || VAR == V_SEG);
+    return MFFT_DMA != 0 && sizeof(T) == 4 && (N == 16384 || N == 8192) &&
+           (VAR == V_PLAIN || VAR == V_SEG || VAR == V_WIN || VAR == V_POW || VAR == V_HANN_POWER);
 }
 
 // Where the packed-form butterflies measured faster (MI355X, complex64, 2^26 points per launch):
@@ -543,14 +544,15 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int TWSRC = DMA ? TW_LDSC : tw_source<T, RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
     constexpr bool VEC = vec_default<T, N, VAR, DMA>();
-    static_assert(!DMA || (SLOTS == 1 && TX > 64 && (VAR == V_PLAIN || VAR == V_SEG) && NPASS >= 2),
-                  "the LDS-DMA pipeline serves plain signals that own their workgroup");
+    static_assert(!DMA || (SLOTS == 1 && TX > 64 && !GENERAL && !FASTSTATS && VAR != V_REAL && NPASS >= 2),
+                  "the LDS-DMA pipeline serves dense complex signals that own their workgroup");
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
     // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
     // offsets instead, 2.4 -> 3.5 TB/s; with 16 points per thread at 8192 the register copy is 5-7 % faster
     // (likewise the 32-point-per-thread kernels: 32 more registers would halve their occupancy,
     // 8192 points Hann + power 3.2 against 4.25 TB/s)
-    constexpr int WINSRC = (MFFT_WIN_SRC == WIN_REG && (N >= MFFT_WIN_BUF_FROM || P >= 32)) ? WIN_BUF : MFFT_WIN_SRC;
+    // (the LDS-DMA kernels need far fewer registers and must not load inside their loop: register copy)
+    constexpr int WINSRC = DMA ? WIN_REG : (MFFT_WIN_SRC == WIN_REG && (N >= MFFT_WIN_BUF_FROM || P >= 32)) ? WIN_BUF : MFFT_WIN_SRC;
     static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -702,6 +704,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             lds_barrier();                                  // both halves are in registers everywhere
             if constexpr (SPLIT) {
                 if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
+            }
+            if constexpr (FASTWIN) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { v[e].x *= wreg[e]; v[e].y *= wreg[e]; }
             }
             MFFT_STAMP(0);
         } else if constexpr (!GENERAL) {
@@ -886,6 +892,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     for (int e = 0; e < P; ++e) {
                         if (t + TX * e < a.n_out) dst[t + TX * e] = s[e];
                     }
+                } else if constexpr (DMA) {
+                    const auto ro = make_rsrc_uniform(dst, (uint32_t)N * sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < P; ++e) buf_st<T, MFFT_NT ? 2 : 0>(ro, (uint32_t)tl * (uint32_t)sizeof(T), TX * e * sizeof(T), s[e]);
                 } else if constexpr (MFFT_FAST_BUF != 0 && TX >= 64) {
                     const auto ro = make_rsrc(dst, (uint32_t)N * sizeof(T));
 #pragma unroll

@@ -27,6 +27,10 @@
 #pragma once
 #include "lds_kernel.h"
 
+#ifndef MFFT_TILE_VEC
+#define MFFT_TILE_VEC 1      // packed-form butterflies (fft_core.h) in the tile passes: +2..7 % on complex64 2^16..2^27 (0 = scalar form)
+#endif
+
 namespace mfft {
 
 // Plain or non-temporal tile accesses, chosen per pass at run time (uniform branch around the
@@ -317,18 +321,18 @@ fft_tile_kernel(const TArgs<T> a)
 
         // ---- G-point DFT of every column, in LDS -----------------------------------
 #if !MFFT_DIAG_NOFFT
-        pass_compute<T, RD, 0, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
+        pass_compute<T, RD, 0, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         if constexpr (NPASS > 1) {
             tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 1, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
+            pass_compute<T, RD, 1, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 2) {
             tile_exchange<T, RD, 1, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 2, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
+            pass_compute<T, RD, 2, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 3) {
             tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
-            pass_compute<T, RD, 3, P, TX, TW_LDS>(v, t, a.tw, nullptr, twl);
+            pass_compute<T, RD, 3, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
 #endif
         // v[e] = output q = t + TX*e of column c

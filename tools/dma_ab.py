@@ -20,15 +20,16 @@ stream = torch.cuda.current_stream().cuda_stream
 warm = torch.randn(1 << 24, device="cuda")
 for _ in range(3000): warm.mul_(1.0001)
 for item in a.sizes.split():
-    k, dtype = map(int, item.split(":"))
+    k, dtype, flags = (list(map(int, item.split(":"))) + [0])[:3]        # log2 n : dtype : flags (1 = Hann, 2 = power)
     n = 1 << k
     batch = (1 << a.points) >> k
     rdt, cdt = (torch.float32, torch.complex64) if dtype == 0 else (torch.float64, torch.complex128)
     bufs = [(torch.view_as_complex(torch.randn((batch, n, 2), dtype=rdt, device="cuda")),
-             torch.empty((batch, n), dtype=cdt, device="cuda")) for _ in range(3)]       # > Infinity Cache in total
+             torch.empty((batch, n), dtype=rdt if flags & 2 else cdt, device="cuda")) for _ in range(3)]       # > Infinity Cache in total
+    win = torch.hann_window(n, periodic=False, dtype=torch.float64, device="cuda") if flags & 1 else None
     x, y = bufs[0]
     res = {}
-    with fft_amd.Plan(n, batch=batch, dtype=dtype) as p:
+    with fft_amd.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
         for tag, env in (("dma", None), ("regs", "1")):
             if env: os.environ["MFFT_NO_DMA"] = env
             else: os.environ.pop("MFFT_NO_DMA", None)
@@ -36,8 +37,10 @@ for item in a.sizes.split():
             rows = [0, 1, batch // 2, batch - 1] + list(range(7, batch, max(1, batch // 23)))
             err = 0.0
             for r in rows:
-                ref = torch.fft.fft(x[r].to(torch.complex128))
-                err = max(err, (torch.linalg.vector_norm(y[r].to(torch.complex128) - ref) / torch.linalg.vector_norm(ref)).item())
+                xr = x[r].to(torch.complex128)
+                ref = torch.fft.fft(xr * win if win is not None else xr)
+                if flags & 2: ref = ref.real ** 2 + ref.imag ** 2
+                err = max(err, (torch.linalg.vector_norm(y[r].to(ref.dtype) - ref) / torch.linalg.vector_norm(ref)).item())
             res[tag] = [err, 1e9]
         for rnd in range(6):
             for tag, env in (("dma", None), ("regs", "1")):
@@ -62,7 +65,7 @@ for item in a.sizes.split():
         names = ["read", "pass0", "exch0", "pass1", "exch1", "pass2", "exch2+dma", "pass3", "scale+stores", "wait"]
         print("   shader-clock ticks per trip, mean over workgroups: " + " | ".join(
             f"{nm} {v:.0f}" for nm, v in zip(names, st.mean(0) / trips)) + f" | total {st.sum(1).mean() / trips:.0f}")
-    bytes_ = 2 * batch * n * (8 if dtype == 0 else 16)
-    print(f"2^{k} x {batch} {'c64' if dtype == 0 else 'c128'}: " + " | ".join(
+    bytes_ = batch * n * (8 if dtype == 0 else 16) * (3 if flags & 2 else 4) // 2
+    print(f"2^{k} x {batch} {'c64' if dtype == 0 else 'c128'} flags {flags}: " + " | ".join(
         f"{t}: {v[1]:7.1f} us {bytes_ / v[1] / 1e3:6.0f} GB/s err {v[0]:.1e}" for t, v in res.items()), flush=True)
     del bufs, x, y
