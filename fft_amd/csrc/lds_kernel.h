@@ -64,8 +64,8 @@
 #define MFFT_R1024 16, 4, 16, 1
 #endif
 #ifndef MFFT_DMA
-#define MFFT_DMA 1           // the largest plain kernels fetch the next signal by LDS-DMA (dma_default): 0 = off, 1 = whole signal
-#endif                       // behind the last exchange, 2 = half of it during the butterflies (split exchanges) and half behind the last exchange
+#define MFFT_DMA 1           // 1 = the largest complex64 kernels fetch the next signal by LDS-DMA behind the last exchange (dma_default)
+#endif
 #ifndef MFFT_VEC
 #define MFFT_VEC -1          // packed-form butterflies (fft_core.h): -1 = where measured faster (vec_default), 0 = never, 1 = every complex64 kernel
 #endif
@@ -387,37 +387,6 @@ __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
     }
 }
 
-// The same exchange with real and imaginary parts taken through LDS one after the other: half the
-// buffer (N scalars), twice the barriers.  The LDS-DMA pipeline uses it to free LDS for the signal
-// that is being fetched.  Entry: nobody still reads the buffer; exit: everybody has read it.
-template <typename T, class RD, int S, int P, int TX, int PADSHIFT>
-__device__ __forceinline__ void pass_exchange_split(cx<T> (&v)[P], int t, T* lds)
-{
-    constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = t + TX * u;
-        const int base = (j / NS) * (NS * R) + (j % NS);
-#pragma unroll
-        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q].x;
-    }
-    lds_barrier();
-#pragma unroll
-    for (int e = 0; e < P; ++e) v[e].x = lds[lds_pad<PADSHIFT>(t + TX * e)];      // .y still holds the old layout
-    lds_barrier();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = t + TX * u;
-        const int base = (j / NS) * (NS * R) + (j % NS);
-#pragma unroll
-        for (int q = 0; q < R; ++q) lds[lds_pad<PADSHIFT>(base + q * NS)] = v[u + U * q].y;
-    }
-    lds_barrier();
-#pragma unroll
-    for (int e = 0; e < P; ++e) v[e].y = lds[lds_pad<PADSHIFT>(t + TX * e)];
-    lds_barrier();
-}
-
 // Copy the twiddles pass S needs for this thread into its register array.
 template <typename T, class RD, int S, int P, int TX>
 __device__ __forceinline__ void preload_twiddles(cx<T>* twr, int t, const cx<T>* __restrict__ tw)
@@ -490,7 +459,8 @@ template <typename T, int N, int VAR> constexpr bool dma_default()
 {
     // complex128 at 8192 points measured 8 % slower this way (473 against 438 us per 2^26 points)
     return MFFT_DMA != 0 && sizeof(T) == 4 && (N == 16384 || N == 8192) &&
-           (VAR == V_PLAIN || VAR == V_SEG || VAR == V_WIN || VAR == V_POW || VAR == V_HANN_POWER);
+           (VAR == V_PLAIN || VAR == V_SEG || VAR == V_WIN || VAR == V_POW || VAR == V_HANN_POWER ||
+            VAR == V_HANN_POWER_STATS || VAR == V_POW_STATS);
 }
 
 // Where the packed-form butterflies measured faster (MI355X, complex64, 2^26 points per launch):
@@ -515,17 +485,17 @@ template <typename T, int N, int VAR> constexpr bool prefetch_default()
     return false;
 }
 
-// LDS-DMA pipeline (DMA = true; one signal per workgroup, plain variants).  With one resident workgroup
-// per CU nothing overlaps a signal's load, butterfly and store phases, and neither registers nor LDS
-// hold a second signal.  Here the NEXT signal is fetched by LDS-DMA -- loads without a register
-// destination.  The exchanges take real and imaginary parts through LDS separately, which halves
-// their buffer and frees room for half a signal: that half is requested when the butterflies begin,
-// the other half into the exchange buffer as soon as the last exchange has been read out of it;
-// the last pass and the stores follow, and the wait at the end of the trip leaves exactly the P
-// stores outstanding, which drain during the next trip.  A CU streams from HBM only as fast as its
-// outstanding requests allow, so what counts is that requests are in flight during the butterflies.
-// Inside the loop every barrier is an LDS-only barrier and every twiddle comes from LDS, because a
-// compiler-counted global load or a __syncthreads() fence would wait for everything outstanding.
+// LDS-DMA pipeline (DMA = true; one signal per workgroup, dense complex input).  With one or two
+// resident workgroups per CU little overlaps a signal's load, butterfly and store phases, and neither
+// registers nor LDS hold a second signal.  Here the NEXT signal is fetched by LDS-DMA -- loads without
+// a register destination -- into the exchange buffer as soon as the last exchange has been read out of
+// it; the last pass and the stores follow, and the wait at the end of the trip leaves exactly the P
+// stores outstanding, which drain while the next signal, already on chip, is being transformed.
+// Inside the loop every barrier is an LDS-only barrier, every twiddle comes from LDS and the window
+// from registers, because a compiler-counted global load or a __syncthreads() fence would wait for
+// everything outstanding.  (Measured and not kept: requesting half of the next signal already when
+// the butterflies begin, into LDS freed by exchanging through a half-size buffer -- twice the
+// barriers; 16384 points plain 215.8 against 215.4 us, Hann 201 against 212, Hann + power 184 against 181.)
 template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR, bool DMA = false>
 __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
 {
@@ -544,7 +514,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     constexpr int TWSRC = DMA ? TW_LDSC : tw_source<T, RD, TX, P, VAR>();
     constexpr bool TWREG = TWSRC == TW_REG;
     constexpr bool VEC = vec_default<T, N, VAR, DMA>();
-    static_assert(!DMA || (SLOTS == 1 && TX > 64 && !GENERAL && !FASTSTATS && VAR != V_REAL && NPASS >= 2),
+    static_assert(!DMA || (SLOTS == 1 && TX > 64 && !GENERAL && VAR != V_REAL && NPASS >= 2),
                   "the LDS-DMA pipeline serves dense complex signals that own their workgroup");
     // the 1024-thread workgroup of 16384 points has no registers to spare for sixteen window samples
     // (140 B/lane of scratch): it reads the L2-resident table through one descriptor and scalar
@@ -559,15 +529,8 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     const int slot = threadIdx.x / TX;
     const int t = threadIdx.x % TX;
     C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
-    // LDS-DMA pipeline: [exchange buffer of LDS_ELEMS scalars, which also receives the second half of the
-    // next signal] [first half of the next signal] [twiddle tables]
-    constexpr bool SPLIT = DMA && MFFT_DMA == 2;
-    constexpr int DMA_EX_BYTES = SPLIT ? (LDS_ELEMS * (int)sizeof(T) + 1023) / 1024 * 1024 : LDS_ELEMS * (int)sizeof(C);
-    constexpr int DMA_HALF_BYTES = N * (int)sizeof(C) / 2;
-    constexpr int DMA_FIRST_AT = SPLIT ? DMA_EX_BYTES : 0;                      // byte offset of the first half's image
-    constexpr int DMA_SECOND_AT = SPLIT ? 0 : DMA_HALF_BYTES;
-    constexpr int DMA_TABLES_AT = SPLIT ? DMA_EX_BYTES + DMA_HALF_BYTES : DMA_EX_BYTES;
-    static_assert(!DMA || DMA_HALF_BYTES <= DMA_EX_BYTES, "the exchange buffer receives half a signal");
+    // LDS-DMA pipeline: [exchange buffer, which also receives the next signal as a lane-linear image] [twiddle tables]
+    constexpr int DMA_TABLES_AT = LDS_ELEMS * (int)sizeof(C);
 
     // ---- tables shared by the workgroup, staged in LDS behind the data slots --
     C* twl = DMA ? reinterpret_cast<C*>(smem_raw + DMA_TABLES_AT)
@@ -640,22 +603,20 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     if constexpr (PREFETCH) {
         if ((int64_t)blockIdx.x < groups) load_fast(vn, (int64_t)blockIdx.x * SLOTS + slot);
     }
-    // LDS-DMA of half a signal as a lane-linear image (element j at byte j * sizeof(C) of its half).
-    // A piece is one wave-instruction = 1 KiB = PE consecutive elements, which lie inside one row of
-    // TX elements, hence inside one segment; wave w moves pieces w, w + NW, ... : the first PPW / 2
-    // of them make up the first half.
+    // LDS-DMA of one signal into the (then idle) exchange buffer as a lane-linear image: element j at
+    // byte j * sizeof(C).  A piece is one wave-instruction = 1 KiB = PE consecutive elements, which lie
+    // inside one row of TX elements, hence inside one segment; wave w moves pieces w, w + NW, ...
     constexpr int PE = 1024 / (int)sizeof(C), NW = BLOCK / 64;
-    constexpr int PPW = DMA ? (N / PE) / NW : 2;
-    static_assert(!DMA || (PPW % 2 == 0 && (PPW / 2) * NW * PE == N / 2), "halves are whole pieces per wave");
+    constexpr int PPW = DMA ? (N / PE) / NW : 1;
+    static_assert(!DMA || PPW * NW * PE == N, "whole pieces per wave");
     const uint32_t stage_lds = (uint32_t)reinterpret_cast<size_t>(smem_raw);       // LDS byte address of the exchange buffer
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const auto dma_half = [&](int64_t bsig, auto half) {
+    const auto dma_signal = [&](int64_t bsig) {
         const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;      // wave-uniform
         const uint32_t lane_off = (threadIdx.x & 63u) * 16u;
         const int q = a.in_lseg - LOG2TX;
-        constexpr int H = decltype(half)::value;
 #pragma unroll
-        for (int i = H * (PPW / 2); i < (H + 1) * (PPW / 2); ++i) {
+        for (int i = 0; i < PPW; ++i) {
             const int piece = wv + NW * i;
             const int j0 = piece * PE;
             int64_t off = j0;
@@ -663,12 +624,9 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                 const int e = j0 >> LOG2TX;
                 off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
             }
-            // first half behind the exchange buffer, second half in it
-            dma_1k(src + off, lane_off, stage_lds + (uint32_t)(H == 0 ? DMA_FIRST_AT : DMA_SECOND_AT - DMA_HALF_BYTES) + (uint32_t)piece * 1024u);
+            dma_1k(src + off, lane_off, stage_lds + (uint32_t)piece * 1024u);
         }
     };
-    using Half0 = std::integral_constant<int, 0>;
-    using Half1 = std::integral_constant<int, 1>;
 #if MFFT_DIAG_STAMPS
     unsigned long long stamp_acc[16] = {};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -677,10 +635,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #define MFFT_STAMP(k) do { } while (0)
 #endif
     if constexpr (DMA) {
-        if ((int64_t)blockIdx.x < groups) {
-            dma_half((int64_t)blockIdx.x, Half0{});
-            dma_half((int64_t)blockIdx.x, Half1{});
-        }
+        if ((int64_t)blockIdx.x < groups) dma_signal((int64_t)blockIdx.x);
         wait_vm<0>();
         lds_barrier();
     }
@@ -697,14 +652,9 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 
         // ---- load ----------------------------------------------------------------
         if constexpr (DMA) {
-            const C* first = reinterpret_cast<const C*>(smem_raw + DMA_FIRST_AT);
-            const C* second = reinterpret_cast<const C*>(smem_raw + DMA_SECOND_AT);
+            const C* stage = reinterpret_cast<const C*>(smem_raw);
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = e < P / 2 ? first[tl + TX * e] : second[tl + TX * (e - P / 2)];
-            lds_barrier();                                  // both halves are in registers everywhere
-            if constexpr (SPLIT) {
-                if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
-            }
+            for (int e = 0; e < P; ++e) v[e] = stage[tl + TX * e];
             if constexpr (FASTWIN) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) { v[e].x *= wreg[e]; v[e].y *= wreg[e]; }
@@ -812,25 +762,15 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 
         // ---- passes ---------------------------------------------------------
 #if !MFFT_DIAG_NOFFT
-        // the exchange buffer is idle from the last exchange on: the second half of the next signal goes there
-        const auto dma_rest = [&]() {
-            if constexpr (!SPLIT) {
-                lds_barrier();                              // every wave has read its exchange results
-                if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half0{});
-            }
-            if (g + gridDim.x < groups) dma_half(g + gridDim.x, Half1{});
+        // the exchange buffer is idle from the last exchange on: the workgroup's next signal goes there
+        const auto dma_next = [&]() {
+            lds_barrier();                                  // every wave has read its exchange results
+            if (g + gridDim.x < groups) dma_signal(g + gridDim.x);
         };
         const auto exchange = [&](auto pass) {
             constexpr int S = decltype(pass)::value;
-            if constexpr (SPLIT) {
-                pass_exchange_split<T, RD, S, P, TX, PADSHIFT>(v, tl, reinterpret_cast<T*>(smem_raw));
-                if constexpr (S == NPASS - 2) dma_rest();
-            } else if constexpr (DMA) {
-                pass_exchange<T, RD, S, P, TX, PADSHIFT, true>(v, tl, lds);
-                if constexpr (S == NPASS - 2) dma_rest();
-            } else {
-                pass_exchange<T, RD, S, P, TX, PADSHIFT>(v, tl, lds);
-            }
+            pass_exchange<T, RD, S, P, TX, PADSHIFT, DMA>(v, tl, lds);
+            if constexpr (DMA && S == NPASS - 2) dma_next();
         };
         pass_compute<T, RD, 0, P, TX, TWSRC, VEC>(v, tl, a.tw, twr, twl);
         MFFT_STAMP(1);
@@ -853,7 +793,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             MFFT_STAMP(7);
         }
 #else
-        if constexpr (DMA) dma_rest();
+        if constexpr (DMA) dma_next();
 #endif
 
         // ---- store: output k = t + TX*e sits in v[e] --------------------------
@@ -1120,9 +1060,7 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
         if (dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
     }
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>((1 << LOG2N) - 1) + 1 + 1) / 2) * 2;
-    constexpr size_t lds = DMA ? (MFFT_DMA == 2 ? ((size_t)LDS_ELEMS * sizeof(T) + 1023) / 1024 * 1024 + ((size_t)sizeof(cx<T>) << LOG2N) / 2
-                                                : (size_t)LDS_ELEMS * sizeof(cx<T>)) +
-                                     twc_total_elems<typename SC::RD>() * sizeof(cx<T>)
+    constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>)
                                : ((SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
     auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR, DMA>;
