@@ -69,6 +69,12 @@
 #ifndef MFFT_VEC
 #define MFFT_VEC -1          // packed-form butterflies (fft_core.h): -1 = where measured faster (vec_default), 0 = never, 1 = every complex64 kernel
 #endif
+// Exchanges address LDS as padded base + immediate: -1 = where measured faster (the LDS-DMA kernels and
+// complex128 at 8192 points: +2 % plain, +6 % Hann + power; elsewhere +-1 %, complex64 4096 points
+// windowed -7 %), 0 = the LDS-DMA kernels only, 1 = everywhere
+#ifndef MFFT_AFFINE
+#define MFFT_AFFINE -1
+#endif
 #ifndef MFFT_DIAG_SKIP
 #define MFFT_DIAG_SKIP 0     // diagnostic builds only: bit 0 = no butterflies / twiddles, bit 1 = no LDS exchanges (results are wrong)
 #endif
@@ -359,6 +365,7 @@ template <typename T, class RD, int S, int P, int TX, int PADSHIFT, bool RAW = f
 __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
+    constexpr bool AFFINE = RAW || MFFT_AFFINE > 0 || (MFFT_AFFINE < 0 && sizeof(T) == 8 && TX * P == 8192);
     if constexpr ((MFFT_DIAG_SKIP & 2) != 0) return;
     if constexpr (TX > 64) {                  // everyone has finished reading the previous contents
         if constexpr (RAW) lds_barrier(); else __syncthreads();
@@ -367,7 +374,7 @@ __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
     for (int u = 0; u < U; ++u) {
         const int j = t + TX * u;
         const int base = (j / NS) * (NS * R) + (j % NS);
-        if constexpr (RAW) {
+        if constexpr (AFFINE) {
             cx<T>* w = lds + lds_pad<PADSHIFT>(base);
 #pragma unroll
             for (int q = 0; q < R; ++q) w[lds_pad_off<PADSHIFT>(q * NS)] = v[u + U * q];
@@ -377,7 +384,7 @@ __device__ __forceinline__ void pass_exchange(cx<T> (&v)[P], int t, cx<T>* lds)
         }
     }
     exchange_sync<TX, RAW>();
-    if constexpr (RAW) {
+    if constexpr (AFFINE) {
         const cx<T>* r = lds + lds_pad<PADSHIFT>(t);
 #pragma unroll
         for (int e = 0; e < P; ++e) v[e] = r[lds_pad_off<PADSHIFT>(TX * e)];

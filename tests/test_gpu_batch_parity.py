@@ -78,16 +78,20 @@ def test_config2_full_batch_against_oracle(fa):
 
 # signals per case: at least three sweeps of the largest persistent grid a length can get
 # (256 CUs x resident workgroups x signals per workgroup), plus a ragged tail
-_BATCH = {1024: 4 * 2048 * 3 + 5, 2048: 2048 * 3 + 5, 4096: 1024 * 3 + 5, 8192: 512 * 3 + 5}
+_BATCH = {1024: 4 * 2048 * 3 + 5, 2048: 2048 * 3 + 5, 4096: 1024 * 3 + 5, 8192: 512 * 3 + 5, 16384: 256 * 3 + 5}
 
 
-@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
-@pytest.mark.parametrize("variant", ["plain", "win", "pow", "hann_power", "hann_power_stats", "real"])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("variant", ["plain", "win", "pow", "hann_power", "hann_power_stats", "pow_stats", "real"])
 def test_multi_trip_ragged_batches(fa, n, variant):
-    """Fast variants of the single-kernel path over several grid sweeps with a ragged last one."""
+    """Fast variants of the single-kernel path over several grid sweeps with a ragged last one.  At
+    8192 and 16384 points every variant but the real-input one runs the LDS-DMA pipeline, whose
+    workgroups fetch their next signal while the current one is stored: the trip count per workgroup
+    differs across the grid here (three or four), and the last trip has no successor."""
     batch = _BATCH[n]
     flags = {"plain": 0, "win": fa.HANN, "pow": fa.POWER, "hann_power": fa.HANN | fa.POWER,
-             "hann_power_stats": fa.HANN | fa.POWER | fa.STATS, "real": fa.REAL_IN}[variant]
+             "hann_power_stats": fa.HANN | fa.POWER | fa.STATS, "pow_stats": fa.POWER | fa.STATS,
+             "real": fa.REAL_IN}[variant]
     scale = 0.5
     if variant == "real":
         x = np.random.default_rng(n).standard_normal((batch, n), dtype=np.float32)
@@ -109,6 +113,38 @@ def test_multi_trip_ragged_batches(fa, n, variant):
         np.testing.assert_allclose(stats[:, 1], ref.sum(axis=1), rtol=1e-5)
         np.testing.assert_allclose(stats[:, 2], (ref * f).sum(axis=1), rtol=0,
                                    atol=1e-5 * np.abs(ref * f).sum(axis=1).max())
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+@pytest.mark.parametrize("batch", [1, 2, 255, 257])
+def test_dma_pipeline_short_batches_and_unaligned_input(fa, n, batch, monkeypatch):
+    """The LDS-DMA kernels at batches below, at and just above one grid sweep (a workgroup with a
+    single trip never fetches a successor), and the same transform from an input that starts 8 bytes
+    off a 16-byte boundary, which the 16-byte DMA pieces cannot read: the library then takes the
+    register-load kernel.  Both against the float64 chain; MFFT_NO_DMA=1 must give the same answer."""
+    import torch
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    x = _rand32((batch, n), n + batch)
+    ref = so.dft(x.astype(np.complex128), engine="numpy")
+    d_buf = torch.zeros(batch * n + 1, dtype=torch.complex64, device="cuda")
+    outs = {}
+    with fa.Plan(n, batch=batch, dtype=fa.C64) as p:
+        for tag, off, env in (("aligned", 0, None), ("shifted", 1, None), ("no_dma", 0, "1")):
+            if env is None:
+                monkeypatch.delenv("MFFT_NO_DMA", raising=False)
+            else:
+                monkeypatch.setenv("MFFT_NO_DMA", env)
+            d_x = d_buf[off:off + batch * n]
+            d_x.copy_(torch.from_numpy(x.reshape(-1)))
+            assert (d_x.data_ptr() % 16 == 0) == (off == 0)
+            d_o = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+            p.exec(d_x, d_o, stream=stream)
+            torch.cuda.synchronize()
+            outs[tag] = d_o.cpu().numpy().reshape(batch, n)
+            assert _worst_row(outs[tag], ref) < TOL[0], (n, batch, tag)
+    # shifted input and MFFT_NO_DMA=1 run the same register-load kernel: bit-identical
+    assert np.array_equal(outs["shifted"], outs["no_dma"])
 
 
 @pytest.mark.parametrize("n,batch", [(512, 9000), (2048, 1600)])
