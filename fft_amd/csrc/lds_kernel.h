@@ -75,6 +75,9 @@
 #ifndef MFFT_AFFINE
 #define MFFT_AFFINE -1
 #endif
+#ifndef MFFT_STATS_F32
+#define MFFT_STATS_F32 1     // complex64 statistics: a thread sums its own values in single precision before the double-precision reduction
+#endif
 #ifndef MFFT_DIAG_SKIP
 #define MFFT_DIAG_SKIP 0     // diagnostic builds only: bit 0 = no butterflies / twiddles, bit 1 = no LDS exchanges (results are wrong)
 #endif
@@ -855,6 +858,21 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             if constexpr (VAR == V_GEN_POWER || FASTSTATS) {
                 if (a.stats != nullptr) {
                     double mx = 0.0, sm = 0.0, sk = 0.0;
+                    if constexpr (sizeof(T) == 4 && MFFT_STATS_F32 != 0) {
+                        // a thread's own P values are accumulated in single precision (the spectrum itself is
+                        // single precision: P more roundings of 6e-8 change nothing), lanes and waves in double
+                        T mxf = 0, smf = 0, skf = 0;
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            const int k = t + TX * e;
+                            const T f = (k < (a.n_out + 1) / 2) ? (T)k : (T)(k - a.n_out);
+                            const T sv = (active && k < a.n_out) ? s[e] : (T)0;
+                            mxf = sv > mxf ? sv : mxf;
+                            smf += sv;
+                            skf += f * sv;
+                        }
+                        mx = mxf; sm = smf; sk = skf;
+                    } else {
 #pragma unroll
                     for (int e = 0; e < P; ++e) {
                         const int k = t + TX * e;
@@ -863,6 +881,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                         mx = sv > mx ? sv : mx;
                         sm += sv;
                         sk += f * sv;
+                    }
                     }
                     constexpr int W = TX < 64 ? TX : 64;
 #pragma unroll
