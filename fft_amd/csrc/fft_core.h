@@ -37,18 +37,22 @@ template <typename T> __device__ __forceinline__ vec2_t<T> v_mi(vec2_t<T> a) { r
 
 template <typename T> MFFT_HD cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> MFFT_HD cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Packed complex product: (a.x b.x, a.x b.y), then + (a.y (-b.y), a.y b.x).  Lane selection and the
+// sign are source modifiers of the two packed instructions (left to the compiler, a third one is
+// spent on a lane move).
+__device__ __forceinline__ vec2_t<float> cmul_pk(vec2_t<float> A, vec2_t<float> B)
+{
+    vec2_t<float> t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(A), "v"(B));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));
+    return r;
+}
+#endif
 template <typename T, bool V = false> MFFT_HD cx<T> cmul(cx<T> a, cx<T> b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (MFFT_VEC_MATH(T, V)) {
-        // (a.x b.x, a.x b.y), then + (a.y (-b.y), a.y b.x): lane selection and the sign are source
-        // modifiers of the two packed instructions (the compiler spends a third one on a lane move)
-        const vec2_t<T> A = to_v(a), B = to_v(b);
-        vec2_t<T> t, r;
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(A), "v"(B));
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(A), "v"(B), "v"(t));
-        return to_c<T>(r);
-    }
+    if constexpr (MFFT_VEC_MATH(T, V)) return to_c<T>(cmul_pk(to_v(a), to_v(b)));
 #endif
     return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }

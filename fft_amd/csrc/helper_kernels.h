@@ -71,11 +71,16 @@ __global__ void chirp_filter_kernel(const cx<T>* chirp, cx<T>* b, int64_t n, int
     }
 }
 
+// Spectrum blockIdx.y (count elements each) divided by its own guarded maximum, which sits
+// max_stride doubles after the previous spectrum's.
 template <typename T>
-__global__ void normalize_kernel(const T* in, T* out, int64_t count, const double* d_max)
+__global__ void normalize_kernel(const T* in, T* out, int64_t count, const double* d_max, int64_t max_stride = 0)
 {
-    const double m = *d_max;
+    const int64_t b = blockIdx.y;
+    const double m = d_max[b * max_stride];
     const T den = (T)(m > 0.0 ? m : 1.0);
+    in += b * count;
+    out += b * count;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (int64_t)gridDim.x * blockDim.x)
         out[i] = in[i] / den;
@@ -539,11 +544,13 @@ __global__ void __launch_bounds__(256) peak_candidates_kernel(const T* S, PeakAr
 // One workgroup per spectrum.  Round r takes the tallest remaining candidate (ties: the larger bin
 // index, as a reversed stable sort would) and strikes every candidate inside its guard band, so a
 // round compares with the newest line only.  out_idx / out_omega / out_height: [batch][want], padded
-// with -1 / 0; out_count: [batch].  cand_val is consumed (struck entries become -1).
+// with -1 / 0; out_count: [batch]; out_E (optional): -omega_hat, the E = -omega convention of
+// final2.py:172, zero beyond the picked lines.  cand_val is consumed (struck entries become -1) and
+// the candidate counter is left at zero for the next scan.
 template <typename T>
 __global__ void __launch_bounds__(1024) peak_pick_kernel(const T* S, PeakArgs a, const int64_t* cand_idx, double* cand_val,
-                                                       const unsigned int* count, int64_t* out_idx, double* out_omega,
-                                                       double* out_height, int* out_count)
+                                                       unsigned int* count, int64_t* out_idx, double* out_omega,
+                                                       double* out_height, int* out_count, double* out_E)
 {
     __shared__ double red_val[16];
     __shared__ int64_t red_idx[16];
@@ -589,7 +596,7 @@ __global__ void __launch_bounds__(1024) peak_pick_kernel(const T* S, PeakArgs a,
     }
     __syncthreads();
     const int got = n_chosen;
-    if (threadIdx.x == 0) out_count[b] = got;
+    if (threadIdx.x == 0) { out_count[b] = got; count[b] = 0; }
     if ((int)threadIdx.x < a.want) {
         const int r = threadIdx.x;
         int64_t i = -1;
@@ -614,16 +621,8 @@ __global__ void __launch_bounds__(1024) peak_pick_kernel(const T* S, PeakArgs a,
         out_idx[b * a.want + r] = i;
         out_omega[b * a.want + r] = wh;
         out_height[b * a.want + r] = h;
+        if (out_E) out_E[b * a.want + r] = r < got ? -wh : 0.0;
     }
-}
-
-// E[b][c] = -omega_hat[b][c]  (E = -omega convention of final2.py:172), zero beyond the picked lines
-__global__ void negate_lines_kernel(const double* omega_hat, const int* count, double* E, int want, int total)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int b = i / want, c = i - b * want;
-    E[i] = c < count[b] ? -omega_hat[i] : 0.0;
 }
 
 // out[b] = f(in[b]) for 1-point "transforms" (np.fft.fft(x, n=1)): the prologue and

@@ -593,6 +593,7 @@ struct Plan {
     char* h_lines = nullptr;      // pinned mirror of the small results in d_lines
     char* h_spec = nullptr;       // pinned landing buffer of the spectra (mfft_lines_host, medium sizes)
     int lines_want = 0;
+    bool lines_dirty = true;       // candidate counters need clearing before the next scan
     int64_t* d_peaks = nullptr;   // {max, sum, centroid} | count | candidate indices (mfft_exec_host_peaks)
     int64_t* h_peaks = nullptr;   // pinned mirror of d_peaks
     int64_t peak_cap = 0;
@@ -1491,6 +1492,7 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
         MFFT_HIP(hipMalloc((void**)&p->d_lines, total));
         MFFT_HIP(hipHostMalloc((void**)&p->h_lines, up_bytes + down_bytes, hipHostMallocDefault));
         p->lines_want = want;
+        p->lines_dirty = true;
     }
     char* d = p->d_lines;
     char* h_up = p->h_lines;
@@ -1517,7 +1519,10 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     a.inv_nd = 1.0 / ((double)n * prm->dt);
     a.dc_thresh = prm->dc_guard; a.guard = prm->guard;
     a.include_dc = prm->include_dc; a.mode = prm->mode; a.want = want;
-    MFFT_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)B, nullptr));
+    // the pick kernel leaves the candidate counters at zero; they are cleared here only after a
+    // (re)allocation or when an earlier call stopped between the two kernels
+    if (p->lines_dirty) MFFT_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)B, nullptr));
+    p->lines_dirty = true;
     int64_t blocks = (n + kPeakChunk - 1) / kPeakChunk;
     if (blocks > 1024) blocks = 1024;
     const int pick_threads = n >= 16384 ? 1024 : 256;
@@ -1525,18 +1530,16 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
         hipLaunchKernelGGL(peak_candidates_kernel<float>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
                            static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt);
         hipLaunchKernelGGL(peak_pick_kernel<float>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
-                           static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n);
+                           static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n, h_gram ? d_E : nullptr);
     } else {
         hipLaunchKernelGGL(peak_candidates_kernel<double>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
                            static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt);
         hipLaunchKernelGGL(peak_pick_kernel<double>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
-                           static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n);
+                           static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n, h_gram ? d_E : nullptr);
     }
     MFFT_HIP(hipGetLastError());
+    p->lines_dirty = false;
     if (h_gram) {
-        const int tot = (int)(B * want);
-        hipLaunchKernelGGL(negate_lines_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, d_om, d_n, d_E, want, tot);
-        MFFT_HIP(hipGetLastError());
         // sub-batches sized to the fixed scratch of the reduction
         const int nchunk = (want + kLsqCols - 1) / kLsqCols;
         int64_t per = (int64_t)(kScratchDoubles / ((size_t)want * nchunk * kLsqSlot));
@@ -1559,11 +1562,15 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     if (h_S) {
         if (normalize) {
             // S / (S.max() if S.max() > 0 else 1.0), per spectrum, in place on the device copy (final2.py:146)
-            for (int64_t b = 0; b < B; ++b) {
-                rc = mfft_normalize_by_max(static_cast<char*>(p->d_out) + (size_t)b * n * rs,
-                                           static_cast<char*>(p->d_out) + (size_t)b * n * rs, n, d_stats + 3 * b, p->dtype, nullptr);
-                if (rc) return rc;
-            }
+            int64_t nblocks = (n + 255) / 256;
+            if (nblocks > 4096) nblocks = 4096;
+            if (p->dtype == MFFT_C64)
+                hipLaunchKernelGGL(normalize_kernel<float>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, nullptr,
+                                   static_cast<const float*>(p->d_out), static_cast<float*>(p->d_out), n, (const double*)d_stats, (int64_t)3);
+            else
+                hipLaunchKernelGGL(normalize_kernel<double>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, nullptr,
+                                   static_cast<const double*>(p->d_out), static_cast<double*>(p->d_out), n, (const double*)d_stats, (int64_t)3);
+            MFFT_HIP(hipGetLastError());
         }
         // A download into a fresh pageable array runs at ~17 GB/s (one staging thread, page faults
         // included); through a pinned landing buffer and the copy threads it is ~2x faster from 1 MiB on
@@ -1597,10 +1604,10 @@ int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const do
     if (blocks > 4096) blocks = 4096;
     if (dtype == MFFT_C64)
         hipLaunchKernelGGL(normalize_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
-                           static_cast<const float*>(d_in), static_cast<float*>(d_out), count, d_max);
+                           static_cast<const float*>(d_in), static_cast<float*>(d_out), count, d_max, (int64_t)0);
     else if (dtype == MFFT_C128)
         hipLaunchKernelGGL(normalize_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
-                           static_cast<const double*>(d_in), static_cast<double*>(d_out), count, d_max);
+                           static_cast<const double*>(d_in), static_cast<double*>(d_out), count, d_max, (int64_t)0);
     else { set_error("bad dtype"); return MFFT_E_INVALID; }
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
