@@ -81,6 +81,11 @@
 #ifndef MFFT_DIAG_SKIP
 #define MFFT_DIAG_SKIP 0     // diagnostic builds only: bit 0 = no butterflies / twiddles, bit 1 = no LDS exchanges (results are wrong)
 #endif
+// 1 = the one-workgroup-per-CU LDS-DMA kernels touch the next signal's lines at the start of a trip, so that
+// the fetch behind the last exchange finds them in L2 (16384 points: Hann +6 %, Hann + power +12 %, plain unchanged)
+#ifndef MFFT_DMA_WARM
+#define MFFT_DMA_WARM 1
+#endif
 #ifndef MFFT_DIAG_STAMPS
 #define MFFT_DIAG_STAMPS 0   // diagnostic builds only: per-workgroup cycle counts of the LDS-DMA pipeline's phases (mfft_diag_read)
 #endif
@@ -201,6 +206,14 @@ __device__ __forceinline__ void dma_1k(const void* sbase, uint32_t voff, uint32_
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// Cache warm-up by LDS-DMA: each lane reads ONE dword (from the line at sbase + voff) into a 256-byte
+// LDS scratch nobody reads, which brings 64 lines into L2 for the price of one instruction.
+__device__ __forceinline__ void dma_touch(const void* sbase, uint32_t voff, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 // wait until at most LEFT vector-memory operations of this wave are outstanding (they retire in issue order)
@@ -541,6 +554,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
     // LDS-DMA pipeline: [exchange buffer, which also receives the next signal as a lane-linear image] [twiddle tables]
     constexpr int DMA_TABLES_AT = LDS_ELEMS * (int)sizeof(C);
+    constexpr int DMA_WARM_AT = DMA_TABLES_AT + twc_total_elems<RD>() * (int)sizeof(C);      // 256 bytes per wave, never read
 
     // ---- tables shared by the workgroup, staged in LDS behind the data slots --
     C* twl = DMA ? reinterpret_cast<C*>(smem_raw + DMA_TABLES_AT)
@@ -644,6 +658,14 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #else
 #define MFFT_STAMP(k) do { } while (0)
 #endif
+    // lines of the wave's own pieces: lane l -> piece wv + NW * (l >> 3), line l & 7 of it (dense input only)
+    constexpr bool WARM = DMA && MFFT_DMA_WARM != 0 && VAR != V_SEG && PPW == 8;
+    const auto dma_warm = [&](int64_t bsig) {
+        const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t voff = ((uint32_t)wv + (uint32_t)NW * (lane >> 3)) * 1024u + (lane & 7u) * 128u;
+        dma_touch(src, voff, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
+    };
     if constexpr (DMA) {
         if ((int64_t)blockIdx.x < groups) dma_signal((int64_t)blockIdx.x);
         wait_vm<0>();
@@ -665,6 +687,9 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             const C* stage = reinterpret_cast<const C*>(smem_raw);
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = stage[tl + TX * e];
+            if constexpr (WARM) {
+                if (g + gridDim.x < groups) dma_warm(g + gridDim.x);
+            }
             if constexpr (FASTWIN) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) { v[e].x *= wreg[e]; v[e].y *= wreg[e]; }
@@ -1086,7 +1111,7 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
         if (dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
     }
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>((1 << LOG2N) - 1) + 1 + 1) / 2) * 2;
-    constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>)
+    constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>) + (MFFT_DMA_WARM != 0 ? BLOCK * 4 : 0)
                                : ((SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
     auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR, DMA>;

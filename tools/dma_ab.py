@@ -56,7 +56,7 @@ for item in a.sizes.split():
     lib = fft_amd._lib.load()
     if hasattr(lib, "mfft_diag_read"):             # diagnostic build: phase ticks of the last DMA launch
         import ctypes, numpy as np
-        with fft_amd.Plan(n, batch=batch, dtype=dtype) as p:
+        with fft_amd.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
             p.exec(x, y, stream=stream); torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * (16 * 256))()
         lib.mfft_diag_read(buf, 16 * 256)
