@@ -208,13 +208,13 @@ __device__ __forceinline__ void dma_1k(const void* sbase, uint32_t voff, uint32_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
-// Cache warm-up by LDS-DMA: each lane reads ONE dword (from the line at sbase + voff) into a 256-byte
+// Cache warm-up by LDS-DMA: each lane reads ONE dword (from the line at its own address) into a 256-byte
 // LDS scratch nobody reads, which brings 64 lines into L2 for the price of one instruction.
-__device__ __forceinline__ void dma_touch(const void* sbase, uint32_t voff, uint32_t lds_dst)
+__device__ __forceinline__ void dma_touch(const void* addr, uint32_t lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
 }
 // wait until at most LEFT vector-memory operations of this wave are outstanding (they retire in issue order)
 template <int LEFT> __device__ __forceinline__ void wait_vm()
@@ -658,13 +658,18 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #else
 #define MFFT_STAMP(k) do { } while (0)
 #endif
-    // lines of the wave's own pieces: lane l -> piece wv + NW * (l >> 3), line l & 7 of it (dense input only)
-    constexpr bool WARM = DMA && MFFT_DMA_WARM != 0 && VAR != V_SEG && PPW == 8;
+    // lines of the wave's own pieces: lane l -> piece wv + NW * (l >> 3), line l & 7 of it
+    constexpr bool WARM = DMA && MFFT_DMA_WARM != 0 && PPW == 8;
     const auto dma_warm = [&](int64_t bsig) {
         const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t voff = ((uint32_t)wv + (uint32_t)NW * (lane >> 3)) * 1024u + (lane & 7u) * 128u;
-        dma_touch(src, voff, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
+        const int j0 = (wv + NW * (int)(lane >> 3)) * PE;                   // first element of the lane's piece
+        int64_t off = j0;
+        if constexpr (VAR == V_SEG) {
+            const int q = a.in_lseg - LOG2TX, e = j0 >> LOG2TX;
+            off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
+        }
+        dma_touch(reinterpret_cast<const char*>(src + off) + (lane & 7u) * 128u, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
     };
     if constexpr (DMA) {
         if ((int64_t)blockIdx.x < groups) dma_signal((int64_t)blockIdx.x);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one plan a few times (for rocprofv3 --kernel-trace --stats):
-    python tools/one_plan.py N BATCH [DTYPE] [FLAGS] [LIBTAG]"""
+    python tools/one_plan.py N BATCH [DTYPE] [FLAGS] [LIBTAG] [LAUNCHES]"""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +19,6 @@ x = torch.view_as_complex(torch.randn((batch, n, 2), dtype=rdt, device="cuda"))
 y = torch.empty((batch, n), dtype=x.dtype if not flags & 2 else rdt, device="cuda")
 h = ctypes.c_void_p()
 assert lib.mfft_plan_1d(ctypes.byref(h), n, n, batch, dtype, flags) == 0, lib.mfft_last_error()
-for _ in range(30):
+for _ in range(int(sys.argv[6]) if len(sys.argv) > 6 else 30):
     assert lib.mfft_exec(h, x.data_ptr(), y.data_ptr(), 1.0, 0.0, 0.0, 1.0, None, None) == 0
 torch.cuda.synchronize()
