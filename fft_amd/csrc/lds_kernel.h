@@ -549,8 +549,10 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     static_assert(BLOCK % TX == 0 && SLOTS >= 1, "block must hold whole signals");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int slot = threadIdx.x / TX;
-    const int t = threadIdx.x % TX;
+    // (the LDS-DMA kernels own their workgroup: a slot the compiler can see is zero keeps the signal's
+    // base addresses provably uniform, i.e. in scalar registers and out of waterfall loops)
+    const int slot = DMA ? 0 : threadIdx.x / TX;
+    const int t = DMA ? (int)threadIdx.x : threadIdx.x % TX;
     C* lds = reinterpret_cast<C*>(smem_raw) + (size_t)slot * LDS_ELEMS;
     // LDS-DMA pipeline: [exchange buffer, which also receives the next signal as a lane-linear image] [twiddle tables]
     constexpr int DMA_TABLES_AT = LDS_ELEMS * (int)sizeof(C);
