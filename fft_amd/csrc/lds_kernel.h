@@ -480,8 +480,7 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 // one workgroup per CU leaves nothing else to overlap with.
 template <typename T, int N, int VAR> constexpr bool dma_default()
 {
-    // complex128 at 8192 points measured 8 % slower this way (473 against 438 us per 2^26 points)
-    return MFFT_DMA != 0 && sizeof(T) == 4 && (N == 16384 || N == 8192) &&
+    return MFFT_DMA != 0 && ((sizeof(T) == 4 && (N == 16384 || N == 8192)) || (sizeof(T) == 8 && N == 8192)) &&
            (VAR == V_PLAIN || VAR == V_SEG || VAR == V_WIN || VAR == V_POW || VAR == V_HANN_POWER ||
             VAR == V_HANN_POWER_STATS || VAR == V_POW_STATS);
 }
@@ -660,18 +659,22 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #else
 #define MFFT_STAMP(k) do { } while (0)
 #endif
-    // lines of the wave's own pieces: lane l -> piece wv + NW * (l >> 3), line l & 7 of it
-    constexpr bool WARM = DMA && MFFT_DMA_WARM != 0 && PPW == 8;
+    // lines of the wave's own pieces: touch k, lane l -> piece wv + NW * (8k + (l >> 3)), line l & 7 of it.
+    // One workgroup per CU only (128 KB signals): with two, the other workgroup covers the latency.
+    constexpr bool WARM = DMA && MFFT_DMA_WARM != 0 && N * (int)sizeof(C) >= 128 * 1024 && PPW % 8 == 0;
     const auto dma_warm = [&](int64_t bsig) {
         const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;
         const uint32_t lane = threadIdx.x & 63u;
-        const int j0 = (wv + NW * (int)(lane >> 3)) * PE;                   // first element of the lane's piece
-        int64_t off = j0;
-        if constexpr (VAR == V_SEG) {
-            const int q = a.in_lseg - LOG2TX, e = j0 >> LOG2TX;
-            off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
+#pragma unroll
+        for (int k = 0; k < PPW / 8; ++k) {
+            const int j0 = (wv + NW * (8 * k + (int)(lane >> 3))) * PE;       // first element of the lane's piece
+            int64_t off = j0;
+            if constexpr (VAR == V_SEG) {
+                const int q = a.in_lseg - LOG2TX, e = j0 >> LOG2TX;
+                off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
+            }
+            dma_touch(reinterpret_cast<const char*>(src + off) + (lane & 7u) * 128u, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
         }
-        dma_touch(reinterpret_cast<const char*>(src + off) + (lane & 7u) * 128u, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
     };
     if constexpr (DMA) {
         if ((int64_t)blockIdx.x < groups) dma_signal((int64_t)blockIdx.x);

@@ -147,6 +147,29 @@ def test_dma_pipeline_short_batches_and_unaligned_input(fa, n, batch, monkeypatc
     assert np.array_equal(outs["shifted"], outs["no_dma"])
 
 
+@pytest.mark.parametrize("variant", ["plain", "win", "pow", "hann_power", "hann_power_stats"])
+def test_multi_trip_complex128_8192(fa, variant):
+    """complex128 at 8192 points (one workgroup per CU, LDS-DMA pipeline with the cache warm-up): three or
+    four trips per workgroup and a ragged end, against the float64 chain to 1e-12."""
+    n, batch = 8192, 256 * 3 + 5
+    flags = {"plain": 0, "win": fa.HANN, "pow": fa.POWER, "hann_power": fa.HANN | fa.POWER,
+             "hann_power_stats": fa.HANN | fa.POWER | fa.STATS}[variant]
+    x = _rand32((batch, n), 77 + len(variant)).astype(np.complex128)
+    with fa.Plan(n, batch=batch, dtype=fa.C128, flags=flags) as p:
+        out, stats = _exec_on_device(fa, p, x)
+    xw = x * so.hanning(n) if flags & fa.HANN else x
+    ref = 0.5 * so.dft(xw, engine="numpy")
+    if flags & fa.POWER:
+        ref = ref.real ** 2 + ref.imag ** 2
+    assert _worst_row(out, ref) < TOL[1], variant
+    if stats is not None:
+        f = so.fftfreq(n) * n
+        np.testing.assert_allclose(stats[:, 0], ref.max(axis=1), rtol=1e-12)
+        np.testing.assert_allclose(stats[:, 1], ref.sum(axis=1), rtol=1e-12)
+        np.testing.assert_allclose(stats[:, 2], (ref * f).sum(axis=1), rtol=0,
+                                   atol=1e-12 * np.abs(ref * f).sum(axis=1).max())
+
+
 @pytest.mark.parametrize("n,batch", [(512, 9000), (2048, 1600)])
 def test_multi_trip_complex128(fa, n, batch):
     x = _rand32((batch, n), n).astype(np.complex128)
