@@ -64,7 +64,7 @@
 #define MFFT_R1024 16, 4, 16, 1
 #endif
 #ifndef MFFT_DMA
-#define MFFT_DMA 1           // 1 = the largest complex64 kernels fetch the next signal by LDS-DMA behind the last exchange (dma_default)
+#define MFFT_DMA 1           // 1 = the 64- and 128-KiB signals fetch their successor by LDS-DMA behind the last exchange (dma_default)
 #endif
 #ifndef MFFT_VEC
 #define MFFT_VEC -1          // packed-form butterflies (fft_core.h): -1 = where measured faster (vec_default), 0 = never, 1 = every complex64 kernel
@@ -81,8 +81,9 @@
 #ifndef MFFT_DIAG_SKIP
 #define MFFT_DIAG_SKIP 0     // diagnostic builds only: bit 0 = no butterflies / twiddles, bit 1 = no LDS exchanges (results are wrong)
 #endif
-// 1 = the one-workgroup-per-CU LDS-DMA kernels touch the next signal's lines at the start of a trip, so that
-// the fetch behind the last exchange finds them in L2 (16384 points: Hann +6 %, Hann + power +12 %, plain unchanged)
+// 1 = the one-workgroup-per-CU LDS-DMA kernels (128-KiB signals) touch the next signal's lines at the start of a
+// trip, so that the fetch behind the last exchange finds them in L2 (complex64 16384 points +6..12 %, complex128
+// 8192 points +6..9 %, for ~7 % more fetched bytes)
 #ifndef MFFT_DMA_WARM
 #define MFFT_DMA_WARM 1
 #endif
@@ -469,15 +470,10 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
     return b;
 }
 
-// Where loading the next signal into registers ahead of the butterflies measured faster (MI355X,
-// 2^26 points per launch).  Signals inside one wave: never (the waves of a workgroup drift apart
-// and overlap loads with butterflies by themselves; 1024 points Hann + power: 139-141 against
-// 134 us).  complex64 2048 points (128-thread workgroups): every fast variant, +2.5 % plain ..
-// +14 % Hann + power; 4096 points: the power-only and statistics variants (+6..7 %) but not the
-// windowed ones (-3..-6 %).  From 8192 points the extra registers spill (8192: 4.7 -> 4.0 TB/s,
-// 16384: 4.1 -> 2.4) and complex128 loses 1..17 % at every length.
-// Where the next signal is fetched by LDS-DMA (below, "LDS-DMA pipeline"): the plain kernels whose
-// one workgroup per CU leaves nothing else to overlap with.
+// Where the next signal is fetched by LDS-DMA (below, "LDS-DMA pipeline"): signals of 64 and 128 KiB, i.e.
+// two or one resident workgroups per CU, dense complex input, every fast variant (+8..30 %).  Measured and
+// left out: 2048 / 4096 complex64 points (-3..-9 %: three or more workgroups per CU overlap by themselves)
+// and 4096 complex128 points (+-0 plain, +3..5 % with power output).
 template <typename T, int N, int VAR> constexpr bool dma_default()
 {
     return MFFT_DMA != 0 && ((sizeof(T) == 4 && (N == 16384 || N == 8192)) || (sizeof(T) == 8 && N == 8192)) &&
@@ -499,6 +495,13 @@ template <typename T, int N, int VAR, bool DMA> constexpr bool vec_default()
     return DMA || N == 2048 || N == 16384;
 }
 
+// Where loading the next signal into registers ahead of the butterflies measured faster (MI355X,
+// 2^26 points per launch).  Signals inside one wave: never (the waves of a workgroup drift apart
+// and overlap loads with butterflies by themselves; 1024 points Hann + power: 139-141 against
+// 134 us).  complex64 2048 points (128-thread workgroups): every fast variant, +2.5 % plain ..
+// +14 % Hann + power; 4096 points: the power-only and statistics variants (+6..7 %) but not the
+// windowed ones (-3..-6 %).  From 8192 points the extra registers spill (8192: 4.7 -> 4.0 TB/s,
+// 16384: 4.1 -> 2.4) and complex128 loses 1..17 % at every length.
 template <typename T, int N, int VAR> constexpr bool prefetch_default()
 {
     if (sizeof(T) != 4) return false;
