@@ -205,6 +205,9 @@ struct Pow2Engine {
     int build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_ = 1, int64_t fs_n_ = 0, int64_t fs_c0_ = 0);
     void release();
     int launches() const { return single ? 1 : (int)passes.size(); }
+    // exec() derives the statistics of a dense power spectrum from a reduction after the last pass
+    // (and so overwrites all of them) whenever the transform takes several passes
+    bool stats_by_reduction(bool power, int64_t out_seg) const { return !single && power && out_seg == 0 && work[0] != nullptr; }
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
 };
 
@@ -764,7 +767,10 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     const bool power = (p->flags & MFFT_POWER) != 0;
     const bool inverse = (p->flags & MFFT_INVERSE) != 0;
     double* stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
-    if (stats) MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)nb, s));
+    // kernels that accumulate the statistics with atomics need them cleared; the multi-pass engine
+    // (chirp-z and long transforms) writes all three values from a reduction of its own
+    if (stats && !p->eng.stats_by_reduction(power, p->lout.seg))
+        MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)nb, s));
     if (demod && tables) {
         const int rc = launch_premul<T>(p, mu, t0, dt, 1, s);
         if (rc) return rc;
