@@ -461,7 +461,9 @@ def test_device_peak_pipeline_matches_reference_steps(fa, dtype):
     batches, and exact height ties."""
     rng = np.random.default_rng(17 + dtype)
     cdt = np.complex64 if dtype == 0 else np.complex128
-    cases = [(300, 16, 3), (1501, 16, 2), (257, 1, 4), (64, 4, 1), (1000, 3, 5)]      # n0, pad, batch
+    # n0, pad, batch.  The last two are noise without padding: ~n/3 local maxima, more than the pick kernel
+    # holds in registers (8 per thread: 2048 below 16384 bins, 8192 from there), i.e. its global-memory form.
+    cases = [(300, 16, 3), (1501, 16, 2), (257, 1, 4), (64, 4, 1), (1000, 3, 5), (12000, 1, 2), (40000, 1, 1)]
     for n0, pad, batch in cases:
         n, dt = n0 * pad, 0.01
         t = np.arange(n0) * dt
