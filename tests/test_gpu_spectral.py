@@ -505,6 +505,46 @@ def test_device_peak_pipeline_matches_reference_steps(fa, dtype):
             p.exec_host_lines(np.ones(64, complex), axis_dt=0.1, guard=1.0, want=2)
 
 
+def test_repeated_calls_on_one_cached_plan(fa):
+    """The estimators keep per-plan device state between calls (staging blocks, candidate counters
+    that the pick kernel leaves at zero, pinned landing buffers).  Repeated calls -- same settings, new
+    data; then other settings on the same plan (another number of lines reallocates the plan's
+    buffers) and back -- must keep giving what the reference gives for each input."""
+    n0, dt = 1501, 0.01
+    t = np.arange(n0) * dt
+    rng = np.random.default_rng(5)
+
+    def signal():
+        E = rng.uniform(-20, 20, 3)
+        w = rng.uniform(0.2, 1.0, 3)
+        return (w[None, :] / w.sum() * np.exp(-1j * E[None, :] * t[:, None])).sum(axis=1)
+
+    def check(f, **kw):
+        E, p, ax, S = fa.fft_from_timeseries(f, t, **kw)
+        Eo, po, axo, So = so.fft_from_timeseries(f, t, **kw)
+        assert E.shape == Eo.shape
+        np.testing.assert_allclose(E, Eo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p, po, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(S, So, rtol=0, atol=1e-12)
+        assert np.array_equal(ax, axo)
+
+    kw3 = dict(n_levels=3, pad_factor=16, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=3)
+    kw4 = dict(n_levels=4, pad_factor=16, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=4)
+    for _ in range(4):
+        check(signal(), **kw3)
+    for _ in range(3):
+        check(signal(), **kw4)             # reallocates the line buffers
+    for _ in range(3):
+        check(signal(), **kw3)
+    blocks = [signal() for _ in range(3)]
+    for _ in range(3):
+        outs = fa.fft_from_timeseries_batch(blocks, t, **kw3)
+        for f, (E, p, _, S) in zip(blocks, outs):
+            Eo, po, _, So = so.fft_from_timeseries(f, t, **kw3)
+            np.testing.assert_allclose(E, Eo, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(S, So, rtol=0, atol=1e-12)
+
+
 def test_close_lines_fit_matches_the_tall_least_squares(fa):
     """Lines 0.6 to 1.2 resolution cells apart (and guard_mult < 1): the weights come from the
     k x k normal equations reduced on the device, the reference solves the tall N0 x k system.  In
