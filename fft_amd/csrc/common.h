@@ -119,7 +119,7 @@ int launch_wave_c128(int log2n, bool win, bool power, bool real_in, const WaveAr
 // Arguments of the global-pass (tile) kernels, see tile_kernel.h
 // ---------------------------------------------------------------------------
 template <typename T> struct TArgs;
-enum { kTileMinLog2G = 4, kTileMaxLog2G = 9, kTileMaxLog2GNarrow = 12 };   // 10..12: four-column tiles, complex64 only
+enum { kTileMinLog2G = 4, kTileMaxLog2G = 9, kTileMaxLog2GNarrow = 12 };   // 10..12: four-column tiles (complex128: 10 only)
 int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s);
 int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s);
 int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class

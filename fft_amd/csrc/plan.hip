@@ -219,14 +219,14 @@ static int tile_log2c(int dtype, int log2g, int narrow)
 // How a length above one LDS residency is split into global passes (log2 of each radix, first
 // pass first).  Fewest passes first; within that the radices are balanced, larger ones first.
 // MFFT_SPLIT="8,8,8" overrides the choice (tuning aid; must multiply to the length).
-static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_inner = 0, int narrow = 0)
+static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_inner = 0, int narrow = 0, int64_t batch = 1)
 {
     out->clear();
     if (const char* env = getenv("MFFT_SPLIT")) {
         int sum = 0;
         for (const char* p = env; *p;) {
             const int v = (int)strtol(p, const_cast<char**>(&p), 10);
-            if (v < kTileMinLog2G || v > (dtype == MFFT_C64 && !log2_inner ? kTileMaxLog2GNarrow : kTileMaxLog2G)) break;
+            if (v < kTileMinLog2G || v > (!log2_inner ? (dtype == MFFT_C64 ? kTileMaxLog2GNarrow : 10) : kTileMaxLog2G)) break;
             out->push_back(v);
             sum += v;
             if (*p == ',') ++p;
@@ -234,9 +234,13 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
         if (sum == log2n && out->size() >= (log2_inner ? 1u : 2u) && out->size() <= 4) return MFFT_OK;
         out->clear();
     }
-    // 2^19 complex64 points: 1024 x 512 in two passes (four-column first pass, XCD-aware order)
-    // measured 107 us per 2^24 points against 156 us for three passes; the larger narrow radices lost.
-    if (dtype == MFFT_C64 && !log2_inner && log2n == 19 && !getenv("MFFT_NO_NARROW_RADIX")) {
+    // 2^19 points: 1024 x 512 in two passes (four-column first pass, XCD-aware order) measured 107 us per
+    // 2^24 complex64 points against 156 us for three passes, and 110 against 135 us per 2^23 complex128
+    // points (the chirp-z length of the reference apps' default transform); the larger narrow radices,
+    // and 1024 x 1024 for complex128 (152 against 135 us), lost.  A single complex128 signal is 128 of those
+    // 256-thread tiles, half the CUs: it keeps three passes (22.7 against 23.6 us plain, but 60 against 56 us
+    // inside the apps' chirp-z).
+    if (!log2_inner && log2n == 19 && (dtype == MFFT_C64 || batch >= 2) && !getenv("MFFT_NO_NARROW_RADIX")) {
         out->push_back(10);
         out->push_back(9);
         return MFFT_OK;
@@ -285,11 +289,11 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     single = false;
     std::vector<int> split;
     const int log2_inner = ilog2(inner);
-    int rc0 = choose_split(log2n, dtype, &split, log2_inner, 0);
+    int rc0 = choose_split(log2n, dtype, &split, log2_inner, 0, batch);
     narrow = 0;
     if (rc0 && inner > 1) {             // fewer columns than a wide tile: the narrow width
         narrow = 1;
-        rc0 = choose_split(log2n, dtype, &split, log2_inner, 1);
+        rc0 = choose_split(log2n, dtype, &split, log2_inner, 1, batch);
     }
     if (rc0) return rc0;
     const int npass = (int)split.size();

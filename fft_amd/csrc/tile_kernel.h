@@ -555,13 +555,13 @@ int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
     case 7: return launch_tile_mode<T, 7>(mode, a, s);
     case 8: return launch_tile_mode<T, 8>(mode, a, s);
     case 9: return launch_tile_mode<T, 9>(mode, a, s);
-    case 10: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 10>(mode, a, s); else break;
+    case 10: return launch_tile_mode<T, 10>(mode, a, s);
 #if MFFT_BIG_RADIX      // 2048 and 4096: measured slower than three passes everywhere; kept for the measurement
     case 11: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 11>(mode, a, s); else break;
     case 12: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 12>(mode, a, s); else break;
 #endif
     }
-    set_error("tile radix outside 16..512 (complex64: ..4096)");
+    set_error("tile radix outside 16..1024 (complex64 tuning builds: ..4096)");
     return MFFT_E_UNSUPPORTED;
 }
 
