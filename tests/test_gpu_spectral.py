@@ -413,7 +413,10 @@ def test_batched_estimator_reproduces_goldens_in_one_call(fa, golden):
         E1, p1, ax1, S1 = fa.fft_from_timeseries(z[f"f_t_{m}"], times, **kw)
         np.testing.assert_allclose(E, E1, rtol=0, atol=1e-12)
         np.testing.assert_allclose(p, p1, rtol=0, atol=1e-12)
-        assert np.array_equal(S_norm, S1) and np.array_equal(Eaxis, ax1)
+        # (a plan of several complex128 signals may split its chirp-z length differently from a plan
+        # of one: same spectrum to rounding, not bit for bit)
+        np.testing.assert_allclose(S_norm, S1, rtol=0, atol=1e-13)
+        assert np.array_equal(Eaxis, ax1)
     # ragged outcomes inside one batch: a silent signal (no line), a real one, a noisy one
     t = np.arange(500) * 0.02
     sigs = [np.zeros(500, complex), np.cos(1.7 * t), _rand(500, 4, np.complex128) + 5 * np.exp(-1j * 2.2 * t)]
