@@ -809,12 +809,12 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         }
 
         // ---- passes ---------------------------------------------------------
-#if !MFFT_DIAG_NOFFT
         // the exchange buffer is idle from the last exchange on: the workgroup's next signal goes there
         const auto dma_next = [&]() {
             lds_barrier();                                  // every wave has read its exchange results
             if (g + gridDim.x < groups) dma_signal(g + gridDim.x);
         };
+#if !MFFT_DIAG_NOFFT
         const auto exchange = [&](auto pass) {
             constexpr int S = decltype(pass)::value;
             pass_exchange<T, RD, S, P, TX, PADSHIFT, DMA>(v, tl, lds);

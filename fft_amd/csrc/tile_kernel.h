@@ -27,6 +27,9 @@
 #pragma once
 #include "lds_kernel.h"
 
+#ifndef MFFT_TILE_TW2
+#define MFFT_TILE_TW2 1      // complex64 inter-pass twiddles as products of two factor sets (0 = a double-precision recurrence per element)
+#endif
 #ifndef MFFT_TILE_VEC
 #define MFFT_TILE_VEC 1      // packed-form butterflies (fft_core.h) in the tile passes: +2..7 % on complex64 2^16..2^27 (0 = scalar form)
 #endif
@@ -310,11 +313,31 @@ fft_tile_kernel(const TArgs<T> a)
             const cx<double> sl = a.tw_lo[(uint32_t)ks & lomask], sh = a.tw_hi[ks >> a.lb];
             cx<double> w = cmul(bl, bh);
             const cx<double> step = cmul(sl, sh);
+            if constexpr (sizeof(T) == 4 && P % 4 == 0 && MFFT_TILE_TW2 != 0) {
+                // complex64: W^(m (t + TX e)) = B_k S_r with e = 4k + r, B_k = base step^(4k), S_r = step^r.
+                // Six double-precision products build the P/4 + 3 factors; the P combinations and the
+                // products with the data are packed single-precision ones (a twiddle is then two
+                // roundings from exact, like a table entry times a derived power in the LDS kernels)
+                // instead of a P-step double recurrence and P double-precision data products.
+                const cx<double> s2 = cmul(step, step), s3 = cmul(s2, step), s4 = cmul(s2, s2);
+                const C_ S1{(T)step.x, (T)step.y}, S2{(T)s2.x, (T)s2.y}, S3{(T)s3.x, (T)s3.y};
 #pragma unroll
-            for (int e = 0; e < P; ++e) {
-                const double xr = (double)v[e].x, xi = (double)v[e].y;
-                v[e] = C_{(T)(xr * w.x - xi * w.y), (T)(xr * w.y + xi * w.x)};
-                w = cmul(w, step);
+                for (int k = 0; k < P / 4; ++k) {
+                    const C_ B{(T)w.x, (T)w.y};
+                    constexpr bool VEC = MFFT_TILE_VEC != 0;
+                    v[4 * k] = cmul<T, VEC>(v[4 * k], B);
+                    v[4 * k + 1] = cmul<T, VEC>(v[4 * k + 1], cmul<T, VEC>(B, S1));
+                    v[4 * k + 2] = cmul<T, VEC>(v[4 * k + 2], cmul<T, VEC>(B, S2));
+                    v[4 * k + 3] = cmul<T, VEC>(v[4 * k + 3], cmul<T, VEC>(B, S3));
+                    w = cmul(w, s4);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    const double xr = (double)v[e].x, xi = (double)v[e].y;
+                    v[e] = C_{(T)(xr * w.x - xi * w.y), (T)(xr * w.y + xi * w.x)};
+                    w = cmul(w, step);
+                }
             }
 #endif
         }
