@@ -87,6 +87,14 @@
 #ifndef MFFT_DMA_WARM
 #define MFFT_DMA_WARM 1
 #endif
+// 1: the centroid sum of the fast statistics variants from compile-time weights (see the epilogue)
+#ifndef MFFT_STATS_CLOSED
+#define MFFT_STATS_CLOSED 1
+#endif
+// 1: the LDS-DMA kernels combine the waves' statistics in LDS and store them; 0: atomics per wave
+#ifndef MFFT_DMA_STATS_LDS
+#define MFFT_DMA_STATS_LDS 1
+#endif
 #ifndef MFFT_DIAG_STAMPS
 #define MFFT_DIAG_STAMPS 0   // diagnostic builds only: per-workgroup cycle counts of the LDS-DMA pipeline's phases (mfft_diag_read)
 #endif
@@ -495,18 +503,17 @@ template <typename T, int N, int VAR, bool DMA> constexpr bool vec_default()
     return DMA || N == 2048 || N == 16384;
 }
 
-// Where loading the next signal into registers ahead of the butterflies measured faster (MI355X,
-// 2^26 points per launch).  Signals inside one wave: never (the waves of a workgroup drift apart
-// and overlap loads with butterflies by themselves; 1024 points Hann + power: 139-141 against
-// 134 us).  complex64 2048 points (128-thread workgroups): every fast variant, +2.5 % plain ..
-// +14 % Hann + power; 4096 points: the power-only and statistics variants (+6..7 %) but not the
-// windowed ones (-3..-6 %).  From 8192 points the extra registers spill (8192: 4.7 -> 4.0 TB/s,
-// 16384: 4.1 -> 2.4) and complex128 loses 1..17 % at every length.
+// Loading the next signal into registers ahead of the butterflies (MFFT_PREFETCH) is off everywhere.
+// Signals inside one wave never gained (the waves of a workgroup drift apart and overlap loads with
+// butterflies by themselves; 1024 points Hann + power: 139-141 against 134 us); from 8192 points the
+// extra registers spill, and complex128 loses 1..17 % at every length.  complex64 2048 / 4096 points
+// gained 2..14 % with the scalar-form butterflies; with the packed form (fewer vector instructions per
+// trip, more room for the other workgroups of the CU to cover the loads) the register cost dominates
+// (MI355X, 2^26 points per launch, prefetch on -> off, GB/s): 2048 points plain 5631 -> 5704, Hann + power
+// 5165 -> 5363, power + statistics 4954 -> 5195, Hann + power + statistics 4600 -> 5066; 4096 points power
+// 5584 -> 5680, power + statistics 5038 -> 5148, Hann + power + statistics 4430 -> 4950.
 template <typename T, int N, int VAR> constexpr bool prefetch_default()
 {
-    if (sizeof(T) != 4) return false;
-    if (N == 2048) return true;
-    if (N == 4096) return VAR == V_POW || VAR == V_POW_STATS || VAR == V_HANN_POWER_STATS;
     return false;
 }
 
@@ -559,6 +566,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     // LDS-DMA pipeline: [exchange buffer, which also receives the next signal as a lane-linear image] [twiddle tables]
     constexpr int DMA_TABLES_AT = LDS_ELEMS * (int)sizeof(C);
     constexpr int DMA_WARM_AT = DMA_TABLES_AT + twc_total_elems<RD>() * (int)sizeof(C);      // 256 bytes per wave, never read
+    constexpr int DMA_STATS_AT = DMA_WARM_AT + (MFFT_DMA_WARM != 0 ? BLOCK * 4 : 0);         // 3 doubles per wave
 
     // ---- tables shared by the workgroup, staged in LDS behind the data slots --
     C* twl = DMA ? reinterpret_cast<C*>(smem_raw + DMA_TABLES_AT)
@@ -896,7 +904,26 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             if constexpr (VAR == V_GEN_POWER || FASTSTATS) {
                 if (a.stats != nullptr) {
                     double mx = 0.0, sm = 0.0, sk = 0.0;
-                    if constexpr (sizeof(T) == 4 && MFFT_STATS_F32 != 0) {
+                    if constexpr (FASTSTATS && MFFT_STATS_CLOSED != 0) {
+                        // all N outputs are kept: output k = t + TX*e has frequency index k for e < P/2 and
+                        // k - N = t + TX*(e - P) beyond, so sum f*s = t * sum s + TX * sum e'*s with
+                        // compile-time weights e' (three instructions per point instead of eight).
+                        // complex64 accumulates a thread's own P values in single precision (the spectrum
+                        // itself is single precision: P more roundings of 6e-8 change nothing).
+                        using A = std::conditional_t<sizeof(T) == 4 && MFFT_STATS_F32 != 0, T, double>;
+                        A mxa = 0, sma = 0, ska = 0;
+#pragma unroll
+                        for (int e = 0; e < P; ++e) {
+                            const A sv = (A)s[e];
+                            mxa = sv > mxa ? sv : mxa;
+                            sma += sv;
+                            ska += (A)(e < P / 2 ? e : e - P) * sv;
+                        }
+                        if (active) {
+                            mx = (double)mxa; sm = (double)sma;
+                            sk = (double)t * (double)sma + (double)TX * (double)ska;
+                        }
+                    } else if constexpr (sizeof(T) == 4 && MFFT_STATS_F32 != 0) {
                         // a thread's own P values are accumulated in single precision (the spectrum itself is
                         // single precision: P more roundings of 6e-8 change nothing), lanes and waves in double
                         T mxf = 0, smf = 0, skf = 0;
@@ -929,7 +956,17 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                         sm += __shfl_xor(sm, o, 64);
                         sk += __shfl_xor(sk, o, 64);
                     }
-                    if (active && (t % W) == 0) {
+                    if constexpr (DMA && MFFT_DMA_STATS_LDS != 0) {
+                        // one signal per workgroup: the waves' partial results meet in LDS after the
+                        // barrier that ends the trip, and wave 0 stores the three numbers.  Atomics here
+                        // would be vector-memory operations issued behind the stores, so the counted wait
+                        // would have to let three more stores drain, and they retire slowly (16 waves on
+                        // three addresses); the sum also becomes independent of the waves' arrival order.
+                        if ((threadIdx.x & 63u) == 0) {
+                            double* red = reinterpret_cast<double*>(smem_raw + DMA_STATS_AT) + 3 * wv;
+                            red[0] = mx; red[1] = sm; red[2] = sk;
+                        }
+                    } else if (active && (t % W) == 0) {
                         double* st = a.stats + 3 * b;
                         if constexpr (TX <= 64) {
                             // the whole signal was reduced inside one wave: plain stores
@@ -1013,6 +1050,24 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
             wait_vm<P>();
             lds_barrier();
             MFFT_STAMP(9);
+            if constexpr (FASTSTATS && MFFT_DMA_STATS_LDS != 0) {
+                if (a.stats != nullptr && wv == 0) {
+                    const int lane = (int)(threadIdx.x & 63u);
+                    const double* red = reinterpret_cast<const double*>(smem_raw + DMA_STATS_AT) + 3 * (lane < NW ? lane : 0);
+                    double mx = lane < NW ? red[0] : 0.0, sm = lane < NW ? red[1] : 0.0, sk = lane < NW ? red[2] : 0.0;
+#pragma unroll
+                    for (int o = NW / 2; o > 0; o >>= 1) {
+                        const double omx = __shfl_xor(mx, o, 64);
+                        mx = omx > mx ? omx : mx;
+                        sm += __shfl_xor(sm, o, 64);
+                        sk += __shfl_xor(sk, o, 64);
+                    }
+                    if (lane == 0) {
+                        double* st = a.stats + 3 * b;
+                        st[0] = mx; st[1] = sm; st[2] = sk;
+                    }
+                }
+            }
         }
     }
 #if MFFT_DIAG_STAMPS
@@ -1124,7 +1179,7 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
         if (dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
     }
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>((1 << LOG2N) - 1) + 1 + 1) / 2) * 2;
-    constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>) + (MFFT_DMA_WARM != 0 ? BLOCK * 4 : 0)
+    constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>) + (MFFT_DMA_WARM != 0 ? BLOCK * 4 : 0) + (BLOCK / 64) * 24
                                : ((SC::RD::npass > 1) ? lds_bytes_for<T, LOG2N, VAR>() : 0);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
     auto kern = fft_lds_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR, DMA>;
