@@ -58,6 +58,8 @@ def parse():
                          "distributed plans (a watchdog abandons that leg after --c-abi-timeout seconds and still "
                          "prints the line)")
     ap.add_argument("--c-abi-timeout", type=float, default=240.0)
+    ap.add_argument("--dist-timeout", type=float, default=240.0,
+                    help="watchdog of the sharded-transform section over torch.distributed (seconds)")
     ap.add_argument("--dist-n2d", type=int, default=16384, help="side of the sharded 2-D transform (config 4)")
     ap.add_argument("--dist-log2n1d", type=int, default=0,
                     help="log2 length of the sharded 1-D transform (config 5); 0 = 31 on 8 ranks, else 28 + log2(ranks)")
@@ -530,30 +532,33 @@ def main():
     if (distributed or args.dist_configs) and not args.no_dist_configs:
         # every rank takes part; rank 0 reports
         torch.cuda.empty_cache()
-        dc = dist_configs(args, world, rank)
-        if rank == 0:
-            line["dist_configs"] = dc
-        if (args.backend == "nccl" or not distributed) and not args.no_dist_c_abi:
-            # Same configs through libmfft's own RCCL calls.  This route has run on RCCL with one rank
-            # and on several in-process ranks only, so it is fenced: if it has not finished in time every
-            # rank leaves (rank 0 after printing the line with what the job measured so far).
-            import threading
+        # Both legs are fenced: a collective that never returns must not cost the job its headline.  When a
+        # leg has not finished in time every rank leaves, rank 0 after printing the line with what the
+        # job has measured so far.
+        import threading
 
+        def fenced(key, seconds, fn):
             def abandon():
                 if rank == 0:
-                    line["dist_configs_c_abi"] = {"error": f"abandoned after {args.c_abi_timeout:.0f} s"}
+                    line[key] = {"error": f"abandoned after {seconds:.0f} s"}
                     print(json.dumps(line), flush=True)
                 os._exit(0)
-            timer = threading.Timer(args.c_abi_timeout, abandon)
+            timer = threading.Timer(seconds, abandon)
             timer.daemon = True
             timer.start()
             try:
-                dcc = dist_configs(args, world, rank, c_abi=True)
-            except Exception as exc:                          # noqa: BLE001
-                dcc = {"error": repr(exc)[:300]}
+                res = fn()
+            except Exception as exc:                          # noqa: BLE001 - a side measurement
+                res = {"error": repr(exc)[:300]}
             timer.cancel()
             if rank == 0:
-                line["dist_configs_c_abi"] = dcc
+                line[key] = res
+
+        fenced("dist_configs", args.dist_timeout, lambda: dist_configs(args, world, rank))
+        if (args.backend == "nccl" or not distributed) and not args.no_dist_c_abi:
+            # Same configs through libmfft's own RCCL calls (this route has run on RCCL with one rank and
+            # on several in-process ranks only).
+            fenced("dist_configs_c_abi", args.c_abi_timeout, lambda: dist_configs(args, world, rank, c_abi=True))
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
