@@ -566,3 +566,20 @@ def test_close_lines_fit_matches_the_tall_least_squares(fa):
         assert E.shape == Eo.shape, (sep, E, Eo)
         np.testing.assert_allclose(E, Eo, rtol=0, atol=1e-9)
         np.testing.assert_allclose(p, po, rtol=0, atol=1e-7)
+
+
+def test_estimators_on_random_line_sets(fa):
+    """Both estimators against the CPU restatement on seeded random inputs the golden files do not
+    hold: 1-6 lines (some closer than the guard band, some at DC), noise, real-valued signals,
+    every keyword of final2.py:115-127 / streamlit_app_combined.py:190 at random values, single
+    and batched calls (tools/fuzz_estimators.py).  E to 1e-8, weights to 1e-6, spectra to 1e-11.
+    Inputs for which the reference's own answer flips under a 1e-13 perturbation (exact height
+    ties of mirrored or side-lobe peaks) are set aside: parity is not defined there."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_estimators as fz
+    del fz.failures[:], fz.unstable[:]
+    count = fz.run(301, 304, 25, verbose=False)
+    assert count >= 140
+    assert not fz.failures, fz.failures[:3]
+    assert len(fz.unstable) < count // 5          # the set-aside cases stay the exception
