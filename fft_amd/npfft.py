@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import gc
+import operator
 import os
 import threading
 from collections import OrderedDict
@@ -160,6 +161,18 @@ def engine_dtype(a: np.ndarray):
     return _lib.C128, True
 
 
+def _norm_factor(n: int, norm, real_dtype) -> float:
+    """The factor numpy applies for `norm`, formed the way numpy forms it: reciprocal and square root
+    in the input's own real precision (numpy/fft/_pocketfft.py, _raw_fft) -- so half- and
+    single-precision inputs carry that precision's rounding of 1/n or 1/sqrt(n), as numpy's do."""
+    if norm is None or norm == "backward":
+        return 1.0
+    rdt = np.result_type(real_dtype, 1.0)
+    if norm == "ortho":
+        return float(np.reciprocal(np.sqrt(n, dtype=rdt)))
+    return float(np.reciprocal(n, dtype=rdt))
+
+
 def _fft_device(a, n, axis, norm):
     """`fft` on a torch CUDA tensor: same semantics, the data never leaves the GPU (torch owns
     the memory and the stream; the transform is libmfft's)."""
@@ -167,7 +180,7 @@ def _fft_device(a, n, axis, norm):
     if a.dim() == 0:
         raise ValueError("fft requires at least a 1-D array")
     n_have = a.shape[axis]
-    n = n_have if n is None else int(n)
+    n = n_have if n is None else operator.index(n)
     if n < 1:
         raise ValueError(f"Invalid number of FFT data points ({n}) specified.")
     if norm not in (None, "backward", "ortho", "forward"):
@@ -188,7 +201,7 @@ def _fft_device(a, n, axis, norm):
                 with plan._lock:
                     plan.exec(x, y, stream=torch.cuda.current_stream().cuda_stream)
                 if norm in ("ortho", "forward"):
-                    y *= (1.0 / np.sqrt(n)) if norm == "ortho" else (1.0 / n)
+                    y *= _norm_factor(n, norm, np.float32 if dtype == _lib.C64 else np.float64)
                 return y
     x = a.movedim(axis, -1)
     if n < n_have:
@@ -202,7 +215,7 @@ def _fft_device(a, n, axis, norm):
     if batch == 0:
         return y.movedim(-1, axis)
     x = x.to(rdt if real_in else cdt).contiguous()
-    scale = {None: 1.0, "backward": 1.0, "ortho": 1.0 / np.sqrt(n), "forward": 1.0 / n}[norm]
+    scale = _norm_factor(n, norm, np.float16 if a.dtype == torch.float16 else np.float32 if dtype == _lib.C64 else np.float64)
     with torch.cuda.device(a.device):
         plan = cached_plan(n, n_in, batch, dtype, _lib.REAL_IN if real_in else 0, device=a.device.index)
         with plan._lock:
@@ -215,7 +228,18 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
     come out as numpy arrays; a torch CUDA tensor is transformed in place on its device and a
     CUDA tensor comes back (no PCIe traffic)."""
     if out is not None:
-        raise NotImplementedError("the `out` argument is not supported")
+        y = fft(a, n=n, axis=axis, norm=norm)
+        if hasattr(y, "is_cuda"):                       # device result into a device tensor
+            if tuple(out.shape) != tuple(y.shape):
+                raise ValueError("output array has wrong shape.")
+            out.copy_(y)
+            return out
+        if not isinstance(out, np.ndarray) or out.shape != y.shape:
+            raise ValueError("output array has wrong shape.")
+        if out.dtype.kind != "c":
+            raise TypeError(f"Cannot cast the transform's {y.dtype} output to {out.dtype}")
+        out[...] = y
+        return out
     if hasattr(a, "is_cuda") and hasattr(a, "data_ptr"):
         if not a.is_cuda:
             a = a.numpy()
@@ -225,7 +249,7 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
     if a.ndim == 0:
         raise ValueError("fft requires at least a 1-D array")
     n_have = a.shape[axis]
-    n = n_have if n is None else int(n)
+    n = n_have if n is None else operator.index(n)     # numpy: a float length is a TypeError
     if n < 1:
         raise ValueError(f"Invalid number of FFT data points ({n}) specified.")
     if norm not in (None, "backward", "ortho", "forward"):
@@ -239,7 +263,7 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
         if plan is not None:
             y = plan.exec_host(np.ascontiguousarray(a, dtype=cdt)).reshape(a.shape)
             if norm in ("ortho", "forward"):
-                y *= (1.0 / np.sqrt(n)) if norm == "ortho" else (1.0 / n)
+                y *= _norm_factor(n, norm, a.real.dtype)
             return y
     x = np.moveaxis(a, axis, -1)
     if n < n_have:
@@ -250,7 +274,7 @@ def fft(a, n=None, axis=-1, norm=None, out=None):
     if batch == 0:
         return np.moveaxis(np.zeros(lead + (n,), dtype=cdt), -1, axis)
     x = np.ascontiguousarray(x, dtype=rdt if real_in else cdt).reshape(batch, n_in)
-    scale = {None: 1.0, "backward": 1.0, "ortho": 1.0 / np.sqrt(n), "forward": 1.0 / n}[norm]
+    scale = _norm_factor(n, norm, a.real.dtype)
     plan = cached_plan(n, n_in, batch, dtype, _lib.REAL_IN if real_in else 0)
     y = plan.exec_host(x, scale=scale)
     return np.moveaxis(y.reshape(lead + (n,)), -1, axis)

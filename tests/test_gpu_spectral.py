@@ -583,3 +583,28 @@ def test_estimators_on_random_line_sets(fa):
     assert count >= 140
     assert not fz.failures, fz.failures[:3]
     assert len(fz.unstable) < count // 5          # the set-aside cases stay the exception
+
+
+def test_fft_signature_corners_and_random_shapes(fa):
+    """numpy.fft.fft's `out`, a non-integer length, half-precision norm factors, and a seeded sweep
+    over dimensions / axes / lengths / norms / dtypes / views against numpy (tools/fuzz_npfft.py)."""
+    import os, sys
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((5, 12)) + 1j * rng.standard_normal((5, 12))
+    out = np.empty((5, 20), dtype=np.complex128)
+    got = fa.fft(a, n=20, out=out)
+    assert got is out and rel_l2(out, np.fft.fft(a, n=20)) < 1e-12
+    with pytest.raises(ValueError):
+        fa.fft(a, n=20, out=np.empty((5, 19), dtype=np.complex128))
+    with pytest.raises(TypeError):
+        fa.fft(a, n=2.5)
+    h = rng.standard_normal(17).astype(np.float16)
+    for norm in ("ortho", "forward"):
+        ref = np.fft.fft(h, norm=norm)
+        got = fa.fft(h, norm=norm)
+        assert got.dtype == ref.dtype == np.complex64 and rel_l2(got, ref) < 1e-6
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_npfft as fz
+    del fz.failures[:]
+    assert fz.run(501, 503, 50, verbose=False) >= 150
+    assert not fz.failures, fz.failures[:3]

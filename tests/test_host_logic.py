@@ -152,3 +152,21 @@ def test_sign_search_matches_one_fit_per_pattern():
         nz = mags > 1e-9                                              # the sign of a zero frequency is free
         assert np.array_equal(signs[nz], best[1][nz]), (mags, signs, best[1])
         assert np.allclose(p, best[2], atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64, np.complex64, np.complex128, np.int32])
+@pytest.mark.parametrize("norm", [None, "backward", "ortho", "forward"])
+def test_norm_factor_is_numpys(dtype, norm):
+    """numpy forms 1/n and 1/sqrt(n) in the input's own real precision (half precision included):
+    the factor handed to the plan must be that very number, read back here from numpy's result
+    for a unit impulse (every bin equals the factor)."""
+    from fft_amd.npfft import _norm_factor
+    for n in (3, 17, 100, 1024, 24016):
+        x = np.zeros(n, dtype=dtype)
+        x[0] = 1
+        ref = np.fft.fft(x, norm=norm)
+        assert float(ref[0].real) == pytest.approx(_norm_factor(n, norm, x.real.dtype), rel=1e-15 if ref.dtype == np.complex128 else 1e-7)
+        # the factor itself is representable in the input's real precision, as numpy's is
+        f = _norm_factor(n, norm, x.real.dtype)
+        rdt = np.result_type(x.real.dtype, 1.0)
+        assert f == float(rdt.type(f))
