@@ -167,3 +167,106 @@ def test_cfg5_2pow31_c128_single_plan():
     torch.cuda.empty_cache()
     want = _direct_bins_1d(x, ks)
     assert np.max(np.abs(got - want)) / math.sqrt(e_in) < 1e-12
+
+
+def _on_rank_threads(comms, fn):
+    """fn(comm) on one host thread per rank of a local communicator (an exchange waits for all)."""
+    import threading
+    out, errs = [None] * len(comms), []
+
+    def work(i):
+        try:
+            out[i] = fn(comms[i])
+        except Exception as e:                                          # noqa: BLE001
+            errs.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(comms))]
+    [t.start() for t in threads]
+    [t.join(timeout=280) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a rank did not finish"
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_multi_rank_shapes_of_the_scaling_runs(P):
+    """The exact shapes `bench.py --gpus P` gives the distributed plans of the C ABI -- 16384 x 16384
+    complex64 over P ranks (both output layouts) and one complex128 signal of 2^(28 + log2 P) points
+    (2^31 on 8 ranks) in natural order -- with the P ranks as a local communicator on the one GPU:
+    slab widths, chunking, segment sizes and 64-bit offsets are those of the multi-GPU job, only the
+    transport differs.  Sampled bins against the DFT evaluated directly in float64."""
+    import torch
+    from fft_amd import dist as fd
+    torch.cuda.set_device(0)
+    lg = 31 if P == 8 else 28 + int(math.log2(P))
+    free, _ = torch.cuda.mem_get_info()
+    if free < (6 * 16 << lg) + (8 << 30):
+        pytest.skip("needs about %d GiB of free device memory" % ((6 * 16 << lg) >> 30))
+    comms = fd.CComm.local(P)
+    try:
+        # ---- config 4
+        n = 16384
+        R, W = n // P, n // P
+        g = torch.Generator(device="cuda").manual_seed(44)
+        a = torch.view_as_complex(torch.randn((n * n, 2), dtype=torch.float32, device="cuda", generator=g))
+        a2 = a.view(n, n)
+        rms = math.sqrt(_energy(a))
+        j = torch.arange(n, dtype=torch.int64, device="cuda")
+        bins = [(0, 0), (1, 0), (0, 1), (R - 1, W), (R, W - 1), (8191, 8192), (16383, 16383), (12345, 6789), (n - R, 1), (1, n - W)]
+        want = []
+        for k0, k1 in bins:
+            w1 = torch.exp(-2j * math.pi * ((j * k1) % n).double() / n)
+            w0 = torch.exp(-2j * math.pi * ((j * k0) % n).double() / n)
+            acc = torch.zeros((), dtype=torch.complex128, device="cuda")
+            for lo in range(0, n, 2048):
+                acc = acc + torch.dot(w0[lo:lo + 2048], a2[lo:lo + 2048].to(torch.complex128) @ w1)
+            want.append(complex(acc.item()))
+        for restore in (False, True):
+            def one(c):
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    f = fd.fft2_slab(a[c.rank * R * n:(c.rank + 1) * R * n], n, n, c, None, restore_layout=restore)
+                    torch.cuda.current_stream().synchronize()
+                    return f
+            outs = _on_rank_threads(comms, one)
+            for (k0, k1), w in zip(bins, want):
+                got = outs[k0 // R][(k0 % R) * n + k1] if restore else outs[k1 // W][k0 * W + k1 % W]
+                assert abs(complex(got.item()) - w) / rms < 1e-5, (P, restore, k0, k1)
+            del outs
+        for c in comms:                                               # free the 2-D plans' buffers
+            for h in c._plans.values():
+                fd._lib.load().mfft_dist_plan_destroy(h)
+            c._plans.clear()
+        del a, a2
+        torch.cuda.empty_cache()
+        # ---- config 5
+        n1, n2 = fd.fourstep_factors(lg)
+        N = n1 * n2
+        cnt = N // P
+        g = torch.Generator(device="cuda").manual_seed(55)
+        x = torch.empty(N, dtype=torch.complex128, device="cuda")
+        xr = torch.view_as_real(x)
+        for lo in range(0, N, 1 << 27):
+            xr[lo:lo + (1 << 27)].normal_(generator=g)
+        e_in = _energy(x)
+
+        def one1(c):
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                y = fd.fft1d_fourstep(x[c.rank * cnt:(c.rank + 1) * cnt], n1, n2, c, None, natural_order=True)
+                torch.cuda.current_stream().synchronize()
+                return y
+        outs = _on_rank_threads(comms, one1)
+        e_out = sum(_energy(o) for o in outs)
+        assert abs(e_out / (N * e_in) - 1.0) < 1e-12                    # Parseval over all ranks
+        ks = [0, 1, cnt - 1, cnt, n1 - 1, n1, n1 + 1, N // 2 - 1, N // 2, N - n2, N - 1, 1234567891 % N, 987654321 % N]
+        got = np.array([complex(outs[k // cnt][k % cnt].item()) for k in ks])
+        del outs
+        for c in comms:
+            c.close()
+        comms = []
+        torch.cuda.empty_cache()
+        want = _direct_bins_1d(x, ks)
+        assert np.max(np.abs(got - want)) / math.sqrt(e_in) < 1e-12
+    finally:
+        for c in comms:
+            c.close()
