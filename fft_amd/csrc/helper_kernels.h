@@ -392,13 +392,19 @@ __global__ void __launch_bounds__(256) lsq_partial_kernel(const LsqBatchArgs a)
 }
 
 // out[sig] = {G (2*m*m, row-major, re/im interleaved), r (2*m), yy}: every value is the sum of its
-// nblk partials in block order, and every value of `out` is written exactly once.
+// nblk <= 64 partials, one wave per value -- lane b holds block b's partial and a fixed butterfly adds
+// them, so the result does not depend on scheduling (a single thread walking the nblk strided
+// partials took 10.6 us for three lines of 8001 samples: a chain of dependent cache misses) -- and
+// every value of `out` is written exactly once.
 __global__ void __launch_bounds__(256) lsq_final_kernel(const double* partial, double* out, int batch, int m, int nchunk,
                                                         int nblk)
 {
     const int64_t total = (int64_t)batch * m * nchunk * kLsqSlot;
     const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < total; i += nwaves) {          // wave-uniform
         const int v = (int)(i % kLsqSlot);
         const int64_t q = i / kLsqSlot;                 // (sig*m + row)*nchunk + chunk
         const int chunk = (int)(q % nchunk);
@@ -414,9 +420,10 @@ __global__ void __launch_bounds__(256) lsq_final_kernel(const double* partial, d
         else if (chunk == 0 && row == 0 && v == 2 * kLsqCols + 2) dst = o + nres - 1;
         if (!dst) continue;
         const double* p = partial + (size_t)q * nblk * kLsqSlot + v;
-        double sum = 0.0;
-        for (int b = 0; b < nblk; ++b) sum += p[(size_t)b * kLsqSlot];
-        *dst = sum;
+        double sum = lane < nblk ? p[(size_t)lane * kLsqSlot] : 0.0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
+        if (lane == 0) *dst = sum;
     }
 }
 

@@ -1370,9 +1370,9 @@ int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d
     // so nothing in the scratch has to start at zero and no stale value of an earlier call is read
     hipLaunchKernelGGL(lsq_partial_kernel, dim3((unsigned)nblk, (unsigned)m, (unsigned)(batch * nchunk)), dim3(256), 0, s, a);
     MFFT_HIP(hipGetLastError());
-    const int64_t total = (int64_t)per_blk;
-    int64_t fblocks = (total + 255) / 256;
-    if (fblocks > 1024) fblocks = 1024;
+    const int64_t total = (int64_t)per_blk;               // one wave per value
+    int64_t fblocks = (total + 3) / 4;
+    if (fblocks > 2048) fblocks = 2048;
     hipLaunchKernelGGL(lsq_final_kernel, dim3((unsigned)fblocks), dim3(256), 0, s, (const double*)d_scratch, d_out,
                        (int)batch, m, nchunk, (int)nblk);
     MFFT_HIP(hipGetLastError());

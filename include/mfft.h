@@ -215,7 +215,9 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
  * held until the process ends), so a call is refused with MFFT_E_UNSUPPORTED when
  * batch * m * ceil(m/16) * 36 doubles exceed it (m = 6: 1213 signals; m = 64: 28); split larger
  * batches.  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
- * two threads) race -- serialise them.  The first call on each device resolves the array's
+ * two threads) race -- serialise them; mfft_lines_host's fit uses the same array (on the null
+ * stream, its launches kept together by a lock inside the library), so a call made on another
+ * stream while a line search runs on that GPU races with it too.  The first call on each device resolves the array's
  * address and should be made outside graph capture.  Results are deterministic (fixed summation
  * order, no atomics) and agree with mfft_lsq_normal_host to rounding (1e-13 relative). */
 int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n,
