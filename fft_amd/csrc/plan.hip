@@ -198,9 +198,6 @@ struct Pow2Engine {
     int narrow = 0;                     // tile width class (TileCols)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
-    int fs_lb = 0;
-    void* d_fs_lo = nullptr;
-    void* d_fs_hi = nullptr;
 
     int build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_ = 1, int64_t fs_n_ = 0, int64_t fs_c0_ = 0);
     void release();
@@ -327,21 +324,6 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         ns <<= gp.log2g;
     }
     if (fs_n > 0 && (!is_pow2(fs_n) || inner == 1)) { set_error("the fused twiddle needs a power-of-two modulus on a column-batched plan"); return MFFT_E_UNSUPPORTED; }
-    if (fs_n > 0) {
-        // two-level table of exp(-2 pi i k / fs_n): k = hi << fs_lb | lo
-        const int bits = ilog2(fs_n);
-        fs_lb = (bits + 1) / 2;
-        const int64_t lo_n = int64_t(1) << fs_lb, hi_n = (fs_n + lo_n - 1) >> fs_lb;
-        re.resize((size_t)lo_n); im.resize((size_t)lo_n);
-        for (int64_t k = 0; k < lo_n; ++k) unit_root(k, fs_n, &re[(size_t)k], &im[(size_t)k]);
-        int rc = upload_complex<double>(re, im, &d_fs_lo);
-        if (rc) return rc;
-        re.resize((size_t)hi_n); im.resize((size_t)hi_n);
-        for (int64_t k = 0; k < hi_n; ++k) unit_root((k << fs_lb) % fs_n, fs_n, &re[(size_t)k], &im[(size_t)k]);
-        rc = upload_complex<double>(re, im, &d_fs_hi);
-        if (rc) return rc;
-        bytes += (lo_n + hi_n) * 2 * (int64_t)sizeof(double);
-    }
     const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
     // Cache policy of the plain tile passes, measured on MI355X with every per-pass combination
     // (2^16..2^24 points, 16 MiB..1 GiB per launch, both precisions): up to about the Infinity
@@ -380,9 +362,9 @@ void Pow2Engine::release()
             if (q) (void)hipFree(q);
     for (void* q : work)
         if (q) (void)hipFree(q);
-    for (void* q : {d_fs_lo, d_fs_hi, stage_in, stage_out})
+    for (void* q : {stage_in, stage_out})
         if (q) (void)hipFree(q);
-    d_fs_lo = d_fs_hi = stage_in = stage_out = nullptr;
+    stage_in = stage_out = nullptr;
     d_tw = nullptr; work[0] = work[1] = nullptr; passes.clear();
 }
 
@@ -539,9 +521,6 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             if (!in_plain || !out_plain) { set_error("column-batched plans take plain complex data"); return MFFT_E_UNSUPPORTED; }
             mode = last ? (fs_n > 0 ? TM_LAST_TWID : TM_LAST_PLAIN) : TM_MID;
             if (last && fs_n > 0) {
-                a.fs_lo = static_cast<const cx<double>*>(d_fs_lo);
-                a.fs_hi = static_cast<const cx<double>*>(d_fs_hi);
-                a.fs_lb = fs_lb;
                 a.fs_mask = (uint64_t)fs_n - 1;
                 a.tw_c0 = fs_c0;
             }

@@ -34,6 +34,10 @@
 #define MFFT_TILE_VEC 1      // packed-form butterflies (fft_core.h) in the tile passes: +2..7 % on complex64 2^16..2^27 (0 = scalar form)
 #endif
 
+#ifndef MFFT_TILE_PREFETCH
+#define MFFT_TILE_PREFETCH 1 // complex128 512-point tiles (one resident workgroup per CU): next tile's loads issued behind the first butterflies
+#endif
+
 namespace mfft {
 
 // Plain or non-temporal tile accesses, chosen per pass at run time (uniform branch around the
@@ -82,12 +86,9 @@ template <typename T> struct TArgs {
     int64_t in_seg, in_seg_stride;     // FIRST: segmented input layout (0 = dense)
     int64_t out_seg, out_seg_stride;   // LAST: segmented output layout (0 = dense)
     // LAST_TWID: out(k, c) *= exp(-2*pi*i * k*(tw_c0 + c) / tw_n), k = row, c = column of the
-    // (n x W) array (the four-step inter-step twiddle), from a two-level table like tw_lo/tw_hi
-    const cx<double>* fs_lo;
-    const cx<double>* fs_hi;
+    // (n x W) array (the four-step inter-step twiddle), evaluated per thread (tile_root)
     int64_t tw_c0;
     uint64_t fs_mask;     // tw_n - 1 (tw_n is a power of two)
-    int fs_lb;
     int lb;
     int log2_w;           // column-batched transforms: W = 1 << log2_w contiguous columns share every
                           // butterfly (NS counts elements, i.e. includes W); 0 for ordinary signals
@@ -99,6 +100,55 @@ template <typename T> struct TArgs {
     int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
     T scale;
 };
+
+// sin and cos of |theta| <= pi/4 in double: Taylor polynomials through theta^15 / theta^16 (truncation
+// 5e-17 / 2e-18), Horner with fused multiply-adds; 1.2e-16 absolute over the whole range.  About
+// thirty instructions where the library's full-range sincospi is several hundred with branches.
+__device__ __forceinline__ void sincos_eighth(double theta, double* s, double* c)
+{
+    const double z = theta * theta;
+    double ps = -1.0 / 1307674368000.0;           // -1/15!
+    ps = fma(ps, z, 1.0 / 6227020800.0);          //  1/13!
+    ps = fma(ps, z, -1.0 / 39916800.0);           // -1/11!
+    ps = fma(ps, z, 1.0 / 362880.0);              //  1/9!
+    ps = fma(ps, z, -1.0 / 5040.0);
+    ps = fma(ps, z, 1.0 / 120.0);
+    ps = fma(ps, z, -1.0 / 6.0);
+    *s = fma(theta * z, ps, theta);
+    double pc = 1.0 / 20922789888000.0;           //  1/16!
+    pc = fma(pc, z, -1.0 / 87178291200.0);        // -1/14!
+    pc = fma(pc, z, 1.0 / 479001600.0);           //  1/12!
+    pc = fma(pc, z, -1.0 / 3628800.0);            // -1/10!
+    pc = fma(pc, z, 1.0 / 40320.0);
+    pc = fma(pc, z, -1.0 / 720.0);
+    pc = fma(pc, z, 1.0 / 24.0);
+    pc = fma(pc, z, -0.5);
+    *c = fma(pc, z, 1.0);
+}
+
+// exp(-2*pi*i*k/n) for n = 2^log2n and k < n, to a few 1e-16 for every k: the angle is
+// reduced to the nearest quarter turn in integers and the remainder, at most an eighth of a turn,
+// goes through sincos_eighth.  Used where a table would be too large to stay in cache: the exponents
+// k*(c0 + c) mod n of the four-step twiddle are scattered over all of n, and two-level tables of
+// 2^15 + 2^16 entries read at four random places per thread cost the last column pass of a
+// 2^31-point transform as much L2 traffic again as its own tile.
+__device__ __forceinline__ cx<double> tile_root(uint64_t k, int log2n)      // n = 2^log2n, 2 <= n <= 2^40
+{
+    const uint64_t k4 = k << 2;
+    const uint64_t q = (k4 + (uint64_t(1) << (log2n - 1))) >> log2n;             // nearest quarter turn
+    const int64_t rem = (int64_t)k4 - (int64_t)(q << log2n);                      // |rem| <= n/2
+    const double inv2n = __longlong_as_double((long long)(1023 - (log2n + 1)) << 52);   // 2^-(log2n + 1), exact
+    double sa, ca;
+    sincos_eighth(3.141592653589793 * ((double)rem * inv2n), &sa, &ca);           // angle = 2*pi*rem/(4n)
+    double c, sn;
+    switch (q & 3) {
+    case 0: c = ca; sn = sa; break;
+    case 1: c = -sa; sn = ca; break;
+    case 2: c = -ca; sn = -sa; break;
+    default: c = sa; sn = -ca; break;
+    }
+    return cx<double>{c, -sn};
+}
 
 // MID: plain strided in / strided out.  FIRST_*: sample order in, contiguous runs out, no
 // inter-pass twiddle.  LAST_*: natural-order bins out.  *_PLAIN = dense full-length complex
@@ -143,11 +193,18 @@ template <int PADSHIFT, int PITCH> __device__ __forceinline__ int tile_addr(int 
     return lds_pad<PADSHIFT>(pos) * PITCH + c;
 }
 
-template <typename T, class RD, int S, int P, int TX, int PADSHIFT, int PITCH>
+// RAW: barriers that wait for LDS traffic only, so that global loads and stores issued earlier stay in
+// flight across the exchange (the prefetching tiles)
+template <bool RAW> __device__ __forceinline__ void tile_barrier()
+{
+    if constexpr (RAW) lds_barrier(); else __syncthreads();
+}
+
+template <typename T, class RD, int S, int P, int TX, int PADSHIFT, int PITCH, bool RAW = false>
 __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>* lds)
 {
     constexpr int R = RD::r[S], U = P / R, NS = RD::ns(S);
-    __syncthreads();
+    tile_barrier<RAW>();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int j = t + TX * u;
@@ -155,7 +212,7 @@ __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>
 #pragma unroll
         for (int q = 0; q < R; ++q) lds[tile_addr<PADSHIFT, PITCH>(base + q * NS, c)] = v[u + U * q];
     }
-    __syncthreads();
+    tile_barrier<RAW>();
 #pragma unroll
     for (int e = 0; e < P; ++e) v[e] = lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)];
 }
@@ -194,6 +251,14 @@ fft_tile_kernel(const TArgs<T> a)
     constexpr int NPASS = RD::npass;
     constexpr int COLPITCH = tile_colpitch<G>();
     constexpr int LDS_ELEMS = PITCH == C ? COLPITCH * C : (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
+    // Prefetch.  A 512-point complex128 tile of 16 columns fills LDS, so ONE 512-thread workgroup is
+    // resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its load,
+    // butterfly and store phases.  These kernels therefore request the next tile into a second
+    // register set as soon as the first butterflies have consumed the current one; the loads travel
+    // during the exchanges, the remaining passes and the stores.  For that the barriers of the
+    // exchanges must not drain the vector-memory counter (tile_barrier<true>).
+    constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
+    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && sizeof(T) == 8 && LOG2G == 9 && LOG2C == 4 && PLAIN_IN;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
@@ -215,13 +280,41 @@ fft_tile_kernel(const TArgs<T> a)
     const int64_t w_off = xcd_map ? (int64_t)(blockIdx.x & 7) * ((total + 7) >> 3) : 0;
     const int64_t w_end = xcd_map ? ((total + 7) >> 3) : total;
     const int64_t w_step = xcd_map ? (gridDim.x >> 3) : gridDim.x;
-    for (int64_t wl = xcd_map ? (blockIdx.x >> 3) : blockIdx.x; wl < w_end; wl += w_step) {
+    // dense tile of super-butterfly group w into registers (the plain modes' load)
+    [[maybe_unused]] const auto load_plain = [&](int64_t w, C_ (&dst)[P]) {
+        const int64_t b = w >> a.log2_tiles;
+        const int64_t j0 = (w & ((int64_t(1) << a.log2_tiles) - 1)) * C;
+        const C_* __restrict__ p = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j0 +
+                                   ((uint32_t)c + (uint32_t)t * (uint32_t)a.L);
+        const int64_t pstep = (int64_t)TX * a.L;
+        if (a.nt & 1) {
+#pragma unroll
+            for (int e = 0; e < P; ++e) { dst[e] = tile_ld<T, true>(p); p += pstep; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < P; ++e) { dst[e] = tile_ld<T, false>(p); p += pstep; }
+        }
+    };
+    // the four table entries behind a tile's inter-pass twiddles (base and step, low and high part)
+    [[maybe_unused]] const auto tw_request = [&](int64_t jj, cx<double> (&o)[4]) {
+        const uint32_t m = (uint32_t)((jj & ns_mask) >> a.log2_w);   // NS / W <= 2^30
+        const uint32_t lomask = (1u << a.lb) - 1;
+        const uint64_t kb = (uint64_t)m * (uint32_t)t;        // base exponent  m*t      < NS*G
+        const uint64_t ks = (uint64_t)m * (uint32_t)TX;       // step exponent  m*TX     < NS*G
+        o[0] = a.tw_lo[(uint32_t)kb & lomask]; o[1] = a.tw_hi[kb >> a.lb];
+        o[2] = a.tw_lo[(uint32_t)ks & lomask]; o[3] = a.tw_hi[ks >> a.lb];
+    };
+    constexpr bool TWIDDLED = !FIRST;                         // every pass but the first multiplies by inter-pass twiddles
+    const int64_t wl0 = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
+    // One tile.  v, tq: its samples and twiddle table entries -- already requested when PF --, vn, tqn:
+    // where a prefetching kernel requests the next tile's.  Returns false past the last tile.
+    const auto trip = [&](int64_t wl, C_ (&v)[P], cx<double> (&tq)[4], [[maybe_unused]] C_ (&vn)[P],
+                          [[maybe_unused]] cx<double> (&tqn)[4]) -> bool {
         const int64_t w = w_off + wl;
-        if (SLIM4 && w >= total) break;
+        if (SLIM4 && w >= total) return false;
         const int64_t b = w >> a.log2_tiles;
         const int64_t j0 = (w & ((int64_t(1) << a.log2_tiles) - 1)) * C;
         const int64_t j = j0 + c;
-        C_ v[P];
 
         // ---- load the G x C tile (row i = t + TX*e, column c) --------------------
         // Four-column tiles address as a wave-uniform 64-bit base (tile origin + e row groups: scalar
@@ -233,7 +326,9 @@ fft_tile_kernel(const TArgs<T> a)
         const C_* __restrict__ in_base = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j0;
         const int64_t pstep = (int64_t)TX * a.L;
         if constexpr (MODE == TM_FIRST_PLAIN) {
-            if constexpr (SLIM4) {
+            if constexpr (PF) {
+                // loaded above / by the previous trip
+            } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
             } else {
@@ -291,8 +386,9 @@ fft_tile_kernel(const TArgs<T> a)
                 if (j + (int64_t)(t + TX * e) * a.L > last) v[e] = C_{0, 0};   // zero padding
             }
         } else {
-            const uint32_t m = (uint32_t)((j & ns_mask) >> a.log2_w);   // NS / W <= 2^30
-            if constexpr (SLIM4) {
+            if constexpr (PF) {
+                // loaded above / by the previous trip
+            } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
             } else {
@@ -306,11 +402,8 @@ fft_tile_kernel(const TArgs<T> a)
                 }
             }
 #if !MFFT_DIAG_NOFFT
-            const uint32_t lomask = (1u << a.lb) - 1;
-            const uint64_t kb = (uint64_t)m * (uint32_t)t;        // base exponent  m*t      < NS*G
-            const uint64_t ks = (uint64_t)m * (uint32_t)TX;       // step exponent  m*TX     < NS*G
-            const cx<double> bl = a.tw_lo[(uint32_t)kb & lomask], bh = a.tw_hi[kb >> a.lb];
-            const cx<double> sl = a.tw_lo[(uint32_t)ks & lomask], sh = a.tw_hi[ks >> a.lb];
+            if constexpr (!PF) tw_request(j, tq);
+            const cx<double> bl = tq[0], bh = tq[1], sl = tq[2], sh = tq[3];
             cx<double> w = cmul(bl, bh);
             const cx<double> step = cmul(sl, sh);
             if constexpr (sizeof(T) == 4 && P % 4 == 0 && MFFT_TILE_TW2 != 0) {
@@ -346,15 +439,30 @@ fft_tile_kernel(const TArgs<T> a)
 #if !MFFT_DIAG_NOFFT
         pass_compute<T, RD, 0, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         if constexpr (NPASS > 1) {
-            tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            tile_exchange<T, RD, 0, P, TX, PADSHIFT, PITCH, PF>(v, t, c, lds);
+            if constexpr (PF) {
+                // Requests behind the first exchange: by now the previous trip's stores, which read the
+                // register set these loads refill, have drained, and the loads have the remaining passes to
+                // arrive.  The next tile's twiddle entries go first: they are needed first (the vector-memory
+                // counter retires in issue order).
+                asm volatile("" ::: "memory");
+                {
+                    // (the last trip asks for its own tile again -- an L2 hit -- rather than branch around the requests)
+                    const int64_t wn = wl + w_step < w_end ? w + w_step : w;
+                    if constexpr (TWIDDLED) tw_request((wn & ((int64_t(1) << a.log2_tiles) - 1)) * C + c, tqn);
+                    asm volatile("" ::: "memory");
+                    load_plain(wn, vn);
+                }
+                asm volatile("" ::: "memory");
+            }
             pass_compute<T, RD, 1, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 2) {
-            tile_exchange<T, RD, 1, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            tile_exchange<T, RD, 1, P, TX, PADSHIFT, PITCH, PF>(v, t, c, lds);
             pass_compute<T, RD, 2, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
         if constexpr (NPASS > 3) {
-            tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH>(v, t, c, lds);
+            tile_exchange<T, RD, 2, P, TX, PADSHIFT, PITCH, PF>(v, t, c, lds);
             pass_compute<T, RD, 3, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
         }
 #endif
@@ -364,13 +472,13 @@ fft_tile_kernel(const TArgs<T> a)
         if constexpr (FIRST) {
             // NS = 1: y[(j0 + c)*G + q] -- the tile is one contiguous run of C*G elements,
             // q fastest.  Turn the registers through LDS so that lanes run along q.
-            __syncthreads();
+            tile_barrier<PF>();
 #pragma unroll
             for (int e = 0; e < P; ++e) {
                 if constexpr (PITCH == C) lds[c * COLPITCH + lds_pad<PADSHIFT>(t + TX * e)] = v[e];
                 else lds[tile_addr<PADSHIFT, PITCH>(t + TX * e, c)] = v[e];
             }
-            __syncthreads();
+            tile_barrier<PF>();
             C_* __restrict__ dst = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j0 * G;
 #pragma unroll
             for (int e = 0; e < P; ++e) {
@@ -405,20 +513,17 @@ fft_tile_kernel(const TArgs<T> a)
         } else if constexpr (MODE == TM_LAST_TWID) {
             // last pass of a column-batched transform with the four-step twiddle folded in:
             // row k = (j >> log2_w) + q*(NS >> log2_w), column cc = tw_c0 + (j & (W-1));
-            // exponent k*cc = base + q*step, built like the inter-pass twiddle above
-            // (keep the table reads below the column DFT: hoisted above it they hold ~50 registers
-            // through the butterflies and cost the second resident workgroup)
+            // exponent k*cc = base + q*step: two roots of unity per thread and a recurrence in double
+            // (kept below the column DFT: evaluated above it the two roots live through the butterflies)
 #pragma unroll
             for (int e = 0; e < P; ++e) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
             const uint64_t cc = (uint64_t)(a.tw_c0 + (j & ((int64_t(1) << a.log2_w) - 1)));
             const uint64_t nsr = (uint64_t)(a.NS >> a.log2_w);
             const uint64_t kb = (((uint64_t)(j >> a.log2_w) + (uint64_t)t * nsr) * cc) & a.fs_mask;
             const uint64_t ks = ((uint64_t)TX * nsr * cc) & a.fs_mask;
-            const uint64_t lomask = (uint64_t(1) << a.fs_lb) - 1;
-            const cx<double> bl = a.fs_lo[kb & lomask], bh = a.fs_hi[kb >> a.fs_lb];
-            const cx<double> sl = a.fs_lo[ks & lomask], sh = a.fs_hi[ks >> a.fs_lb];
-            cx<double> w = cmul(bl, bh);
-            const cx<double> step = cmul(sl, sh);
+            const int fs_log2n = __builtin_popcountll(a.fs_mask);
+            cx<double> w = tile_root(kb, fs_log2n);
+            const cx<double> step = tile_root(ks, fs_log2n);
             C_* __restrict__ q = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j + (int64_t)t * a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
 #pragma unroll
@@ -502,6 +607,35 @@ fft_tile_kernel(const TArgs<T> a)
                     }
                 }
             }
+        }
+        return true;
+    };
+    if constexpr (PF) {
+        // Two register sets that swap roles from trip to trip (no copies: a trip's stores are still
+        // reading the set the next trip's prefetch must not yet overwrite).  The first tile is requested
+        // and awaited before the loop, so that inside it the only loads pending at the top of a trip
+        // are those the previous trip issued ahead of its stores.
+        C_ va[P], vb[P];
+        cx<double> ta[4], tb[4];
+        if (wl0 < w_end) {
+            if constexpr (TWIDDLED) tw_request(((w_off + wl0) & ((int64_t(1) << a.log2_tiles) - 1)) * C + c, ta);
+            load_plain(w_off + wl0, va);
+#pragma unroll
+            for (int e = 0; e < P; ++e) asm volatile("" : "+v"(va[e].x), "+v"(va[e].y));
+            if constexpr (TWIDDLED) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ta[i].x), "+v"(ta[i].y));
+            }
+        }
+        for (int64_t wl = wl0; wl < w_end; wl += 2 * w_step) {
+            trip(wl, va, ta, vb, tb);
+            if (wl + w_step < w_end) trip(wl + w_step, vb, tb, va, ta);
+        }
+    } else {
+        for (int64_t wl = wl0; wl < w_end; wl += w_step) {
+            C_ v[P];
+            cx<double> tq[4];
+            if (!trip(wl, v, tq, v, tq)) break;
         }
     }
 }
