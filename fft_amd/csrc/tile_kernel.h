@@ -251,14 +251,17 @@ fft_tile_kernel(const TArgs<T> a)
     constexpr int NPASS = RD::npass;
     constexpr int COLPITCH = tile_colpitch<G>();
     constexpr int LDS_ELEMS = PITCH == C ? COLPITCH * C : (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
-    // Prefetch.  A 512-point complex128 tile of 16 columns fills LDS, so ONE 512-thread workgroup is
-    // resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its load,
-    // butterfly and store phases.  These kernels therefore request the next tile into a second
+    // Prefetch.  A complex128 tile of 512 points x 16 columns or 256 x 32 fills LDS, so ONE 512-thread
+    // workgroup is resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its
+    // load, butterfly and store phases.  These kernels therefore request the next tile into a second
     // register set as soon as the first butterflies have consumed the current one; the loads travel
     // during the exchanges, the remaining passes and the stores.  For that the barriers of the
     // exchanges must not drain the vector-memory counter (tile_barrier<true>).
     constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
-    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && sizeof(T) == 8 && LOG2G == 9 && LOG2C == 4 && PLAIN_IN;
+    // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
+    // pass -6 %, middle passes +6 % -- and keep the plain loop.)
+    constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
+    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && sizeof(T) == 8 && ONE_WG && BLOCK == 512 && NPASS >= 3 && PLAIN_IN;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
