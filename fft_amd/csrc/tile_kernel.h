@@ -307,12 +307,10 @@ fft_tile_kernel(const TArgs<T> a)
         o[0] = a.tw_lo[(uint32_t)kb & lomask]; o[1] = a.tw_hi[kb >> a.lb];
         o[2] = a.tw_lo[(uint32_t)ks & lomask]; o[3] = a.tw_hi[ks >> a.lb];
     };
-    constexpr bool TWIDDLED = !FIRST;                         // every pass but the first multiplies by inter-pass twiddles
     const int64_t wl0 = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
-    // One tile.  v, tq: its samples and twiddle table entries -- already requested when PF --, vn, tqn:
-    // where a prefetching kernel requests the next tile's.  Returns false past the last tile.
-    const auto trip = [&](int64_t wl, C_ (&v)[P], cx<double> (&tq)[4], [[maybe_unused]] C_ (&vn)[P],
-                          [[maybe_unused]] cx<double> (&tqn)[4]) -> bool {
+    // One tile.  v: its samples -- already requested when PF --, vn: where a prefetching kernel requests
+    // the next tile's.  Returns false past the last tile.
+    const auto trip = [&](int64_t wl, C_ (&v)[P], [[maybe_unused]] C_ (&vn)[P]) -> bool {
         const int64_t w = w_off + wl;
         if (SLIM4 && w >= total) return false;
         const int64_t b = w >> a.log2_tiles;
@@ -405,10 +403,21 @@ fft_tile_kernel(const TArgs<T> a)
                 }
             }
 #if !MFFT_DIAG_NOFFT
-            if constexpr (!PF) tw_request(j, tq);
-            const cx<double> bl = tq[0], bh = tq[1], sl = tq[2], sh = tq[3];
-            cx<double> w = cmul(bl, bh);
-            const cx<double> step = cmul(sl, sh);
+            cx<double> w, step;
+            if constexpr (PF) {
+                // evaluated, not read: table loads issued here would retire behind the previous trip's
+                // stores (the counter is in order), i.e. drain them, and prefetched entries cost sixteen
+                // registers these kernels do not have
+                const uint32_t m = (uint32_t)((j & ns_mask) >> a.log2_w);
+                const int log2m = a.log2_ns - a.log2_w + LOG2G;           // the tables' modulus (NS / W) * G
+                w = tile_root((uint64_t)m * (uint32_t)t, log2m);
+                step = tile_root((uint64_t)m * (uint32_t)TX, log2m);
+            } else {
+                cx<double> tq[4];
+                tw_request(j, tq);
+                w = cmul(tq[0], tq[1]);
+                step = cmul(tq[2], tq[3]);
+            }
             if constexpr (sizeof(T) == 4 && P % 4 == 0 && MFFT_TILE_TW2 != 0) {
                 // complex64: W^(m (t + TX e)) = B_k S_r with e = 4k + r, B_k = base step^(4k), S_r = step^r.
                 // Six double-precision products build the P/4 + 3 factors; the P combinations and the
@@ -446,16 +455,10 @@ fft_tile_kernel(const TArgs<T> a)
             if constexpr (PF) {
                 // Requests behind the first exchange: by now the previous trip's stores, which read the
                 // register set these loads refill, have drained, and the loads have the remaining passes to
-                // arrive.  The next tile's twiddle entries go first: they are needed first (the vector-memory
-                // counter retires in issue order).
+                // arrive.  (The last trip asks for its own tile again -- an L2 hit -- rather than branch
+                // around the requests.)
                 asm volatile("" ::: "memory");
-                {
-                    // (the last trip asks for its own tile again -- an L2 hit -- rather than branch around the requests)
-                    const int64_t wn = wl + w_step < w_end ? w + w_step : w;
-                    if constexpr (TWIDDLED) tw_request((wn & ((int64_t(1) << a.log2_tiles) - 1)) * C + c, tqn);
-                    asm volatile("" ::: "memory");
-                    load_plain(wn, vn);
-                }
+                load_plain(wl + w_step < w_end ? w + w_step : w, vn);
                 asm volatile("" ::: "memory");
             }
             pass_compute<T, RD, 1, P, TX, TW_LDS, (MFFT_TILE_VEC != 0)>(v, t, a.tw, nullptr, twl);
@@ -619,26 +622,19 @@ fft_tile_kernel(const TArgs<T> a)
         // and awaited before the loop, so that inside it the only loads pending at the top of a trip
         // are those the previous trip issued ahead of its stores.
         C_ va[P], vb[P];
-        cx<double> ta[4], tb[4];
         if (wl0 < w_end) {
-            if constexpr (TWIDDLED) tw_request(((w_off + wl0) & ((int64_t(1) << a.log2_tiles) - 1)) * C + c, ta);
             load_plain(w_off + wl0, va);
 #pragma unroll
             for (int e = 0; e < P; ++e) asm volatile("" : "+v"(va[e].x), "+v"(va[e].y));
-            if constexpr (TWIDDLED) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ta[i].x), "+v"(ta[i].y));
-            }
         }
         for (int64_t wl = wl0; wl < w_end; wl += 2 * w_step) {
-            trip(wl, va, ta, vb, tb);
-            if (wl + w_step < w_end) trip(wl + w_step, vb, tb, va, ta);
+            trip(wl, va, vb);
+            if (wl + w_step < w_end) trip(wl + w_step, vb, va);
         }
     } else {
         for (int64_t wl = wl0; wl < w_end; wl += w_step) {
             C_ v[P];
-            cx<double> tq[4];
-            if (!trip(wl, v, tq, v, tq)) break;
+            if (!trip(wl, v, v)) break;
         }
     }
 }
