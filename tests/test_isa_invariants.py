@@ -100,3 +100,41 @@ def test_lds_dma_kernels_keep_their_counted_wait(tmp_path):
             # a descriptor the compiler cannot prove uniform costs a waterfall loop per store
             assert not any(t.startswith("v_readfirstlane") for t in body[len(body) // 2:]), (name, "waterfall loop around a store")
     assert checked >= 8, f"only {checked} LDS-DMA kernels found in {LIB}"
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libmfft.so is not built")
+@pytest.mark.skipif(not all(_tool(t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")),
+                    reason="ROCm LLVM tools not found")
+def test_prefetching_tile_kernels_request_the_next_tile_between_exchanges(tmp_path):
+    """The 512-point complex128 tile passes (fft_amd/csrc/tile_kernel.h, PF) run one workgroup per CU and
+    overlap its phases by requesting the next tile into a second register set behind the first exchange.
+    That holds only while the request stays between two exchanges' barriers (a __syncthreads() fence or
+    a compiler that sinks the loads to their use would undo it), the barriers are LDS-only, and the
+    kernels fit 256 registers without spilling inside the loop."""
+    objdump = _tool("llvm-objdump")
+    checked = 0
+    for co in _code_objects(tmp_path):
+        syms = subprocess.run([objdump, "-t", str(co)], capture_output=True, text=True, check=True).stdout
+        if "fft_tile_kernelIdLi9ELi4E" not in syms:
+            continue
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True, check=True).stdout
+        for name, (_, ins) in _functions(dis).items():
+            m = re.search(r"fft_tile_kernelIdLi9ELi4ELi(\d)E", name)
+            if not m or int(m.group(1)) not in (0, 1, 3, 6):          # the plain modes: middle, first, last, last + twiddle
+                continue
+            checked += 1
+            back = [(adr - tgt, tgt, adr) for adr, _, tgt in ins if tgt is not None and tgt < adr]
+            assert back, name
+            _, lo, hi = max(back)
+            body = [t for adr, t, _ in ins if lo <= adr <= hi]
+            assert not any(t.startswith(("scratch_load", "scratch_store")) for t in body), (name, "spills inside the loop")
+            # positions of barriers and of sample loads: some load must have a barrier before AND after it
+            bars = [i for i, t in enumerate(body) if t.startswith("s_barrier")]
+            loads = [i for i, t in enumerate(body) if t.startswith("global_load_dwordx4")]
+            assert len(bars) >= 8 and loads, (name, len(bars), len(loads))    # two trips x two exchanges x two barriers
+            assert any(bars[0] < i < bars[-1] for i in loads), (name, "the next tile is not requested between the exchanges")
+            # a full fence before a barrier would drain the request
+            for b in bars:
+                window = " ".join(body[max(0, b - 3):b])
+                assert "vmcnt(0)" not in window, (name, "a barrier of the exchange drains the vector-memory counter")
+    assert checked >= 4, f"only {checked} prefetching tile kernels found in {LIB}"
