@@ -261,7 +261,7 @@ fft_tile_kernel(const TArgs<T> a)
     // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
     // pass -6 %, middle passes +6 % -- and keep the plain loop.)
     constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
-    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && sizeof(T) == 8 && ONE_WG && BLOCK == 512 && NPASS >= 3 && PLAIN_IN;
+    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && ONE_WG && BLOCK == 512 && NPASS >= 3 && PLAIN_IN;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
