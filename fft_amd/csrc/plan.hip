@@ -286,7 +286,8 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     single = false;
     std::vector<int> split;
     const int log2_inner = ilog2(inner);
-    int rc0 = choose_split(log2n, dtype, &split, log2_inner, 0, batch);
+    const bool try_wide = !(inner > 1 && getenv("MFFT_NARROW_COLUMNS"));   // tuning aid: narrow tiles for every column-batched plan
+    int rc0 = try_wide ? choose_split(log2n, dtype, &split, log2_inner, 0, batch) : MFFT_E_UNSUPPORTED;
     narrow = 0;
     if (rc0 && inner > 1) {             // fewer columns than a wide tile: the narrow width
         narrow = 1;

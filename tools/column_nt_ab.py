@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Cache policy of a column-batched plan's passes, alternated inside one process (MFFT_TILE_NT_PASS is read
 when a plan is built; bit 0 = streaming loads, bit 1 = streaming stores, one value per pass):
-    python tools/column_nt_ab.py LOG2N LOG2INNER DTYPE POLICY [POLICY ...]     ("default" = the library's choice)"""
+    python tools/column_nt_ab.py LOG2N LOG2INNER DTYPE POLICY [POLICY ...]     ("default" = the library's choice,
+"narrow" = the narrow tile width, MFFT_NARROW_COLUMNS, with the default policy)"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,9 +18,11 @@ s = torch.cuda.current_stream().cuda_stream
 res = {}
 for rnd in range(3):
     for pol in sys.argv[4:]:
-        if pol == "default":
-            os.environ.pop("MFFT_TILE_NT_PASS", None)
-        else:
+        os.environ.pop("MFFT_TILE_NT_PASS", None)
+        os.environ.pop("MFFT_NARROW_COLUMNS", None)
+        if pol == "narrow":                                   # narrow tiles instead of a cache policy
+            os.environ["MFFT_NARROW_COLUMNS"] = "1"
+        elif pol != "default":
             os.environ["MFFT_TILE_NT_PASS"] = pol
         p = ColumnPlan(n, inner, 1, dtype, twiddle=(n * inner * 8, 3 * inner))
         for _ in range(2):
