@@ -253,10 +253,11 @@ fft_tile_kernel(const TArgs<T> a)
     constexpr int LDS_ELEMS = PITCH == C ? COLPITCH * C : (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
     // Prefetch.  A complex128 tile of 512 points x 16 columns or 256 x 32 fills LDS, so ONE 512-thread
     // workgroup is resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its
-    // load, butterfly and store phases.  These kernels therefore request the next tile into a second
-    // register set as soon as the first butterflies have consumed the current one; the loads travel
-    // during the exchanges, the remaining passes and the stores.  For that the barriers of the
-    // exchanges must not drain the vector-memory counter (tile_barrier<true>).
+    // load, butterfly and store phases.  The 512-point kernels therefore request the next tile into a
+    // second register set behind their first exchange; the loads travel during the remaining two passes
+    // and the stores.  For that the barriers of the exchanges must not drain the vector-memory counter
+    // (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
+    // (tile_root) instead of read from the tables.
     constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
     // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
     // pass -6 %, middle passes +6 % -- and keep the plain loop.)
