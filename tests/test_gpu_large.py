@@ -25,6 +25,46 @@ def fa():
     return fft_amd
 
 
+@pytest.mark.parametrize("split,log2n,batch", [("9,9,4", 22, 1), ("9,9,5", 23, 1), ("9,5,9", 23, 1), ("5,9,9", 23, 1), ("9,9,4", 22, 3)])
+def test_prefetching_512_point_tiles_against_numpy(fa, monkeypatch, split, log2n, batch):
+    """The 512-point complex128 tile passes keep a second register set and request the next tile behind
+    their first exchange; the sets swap roles from trip to trip.  Forced onto lengths numpy still
+    transforms in a second (MFFT_SPLIT is read when the plan is built), as first, middle and last pass,
+    with two to twelve trips per workgroup (odd and even counts), all bins against the oracle's engine."""
+    monkeypatch.setenv("MFFT_SPLIT", split)
+    n = 1 << log2n
+    x = _rand((batch, n), 77 + log2n + batch, np.complex128)
+    with fa.Plan(n, batch=batch, dtype=1) as p:
+        assert p.launches == 3
+        y = p.exec_host(x)
+    assert rel_l2(y, so.dft(x, engine="numpy")) < TOL[1]
+
+
+def test_large_complex128_plans_on_sampled_bins(fa):
+    """2^25 .. 2^27 complex128 points (512-point first / middle / last passes as the library itself picks
+    them): sampled bins against the DFT evaluated directly in float64, and Parseval."""
+    import math
+    import torch
+    from test_gpu_fullsize import _direct_bins_1d, _energy
+    torch.cuda.set_device(0)
+    for lg in (25, 26, 27):
+        n = 1 << lg
+        g = torch.Generator(device="cuda").manual_seed(lg)
+        x = torch.empty(n, dtype=torch.complex128, device="cuda")
+        torch.view_as_real(x).normal_(generator=g)
+        y = torch.empty_like(x)
+        with fa.Plan(n, dtype=fa.C128) as p:
+            assert p.launches == 3
+            p.exec(x, y, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        e_in = _energy(x)
+        assert abs(_energy(y) / (n * e_in) - 1.0) < 1e-12
+        ks = [0, 1, 511, 512, 513, n // 2 - 1, n // 2, n - 512, n - 1, 123456789 % n, 98765432 % n]
+        got = y[torch.tensor(ks, device="cuda")].cpu().numpy()
+        want = _direct_bins_1d(x, ks)
+        assert np.max(np.abs(got - want)) / math.sqrt(e_in) < 1e-12, lg
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("log2n", [14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_tiled_pow2(fa, dtype, log2n):
