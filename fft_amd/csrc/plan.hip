@@ -325,6 +325,8 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         ns <<= gp.log2g;
     }
     if (fs_n > 0 && (!is_pow2(fs_n) || inner == 1)) { set_error("the fused twiddle needs a power-of-two modulus on a column-batched plan"); return MFFT_E_UNSUPPORTED; }
+    if (fs_n > (int64_t(1) << 40)) { set_error("fused twiddle modulus above 2^40"); return MFFT_E_UNSUPPORTED; }   // tile_root's integer reduction
+    if (fs_n == 1) fs_n = 0;            // exp(-2 pi i k c / 1) = 1: nothing to multiply by
     const size_t wbytes = (size_t)n * (size_t)inner * (size_t)batch * 2 * real_size(dtype);
     // Cache policy of the plain tile passes, measured on MI355X with every per-pass combination
     // (2^16..2^24 points, 16 MiB..1 GiB per launch, both precisions): up to about the Infinity

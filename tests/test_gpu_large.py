@@ -165,6 +165,19 @@ def test_column_batched_plans(fa, dtype):
     c = (c0 + np.arange(inner))[None, :].astype(np.float64)
     ref = np.fft.fft(x[0].astype(np.complex128), axis=0) * np.exp(-2j * np.pi * (k * c) / n_total)
     assert rel_l2(y[0], ref) < TOL[dtype]
+    # the twiddle's roots are evaluated per thread (quarter-turn reduction + small-angle polynomial): moduli
+    # from the degenerate ones up to 2^40, exponents k*c reduced exactly on the host
+    n, inner = 256, wmin
+    x = _rand((1, n, inner), 7, cdt)
+    base = np.fft.fft(x[0].astype(np.complex128), axis=0)
+    for n_total, c0 in ((1, 0), (2, 1), (4, 3), (1 << 12, 5), (1 << 31, (1 << 20) + 7), (1 << 40, (1 << 33) + 12345)):
+        with fa.ColumnPlan(n, inner, dtype=dtype, twiddle=(n_total, c0)) as p:
+            y = p.exec_host(x)
+        kc = np.array([[(int(k) * (c0 + int(c))) % n_total for c in range(inner)] for k in range(n)], dtype=np.float64)
+        ref = base * np.exp(-2j * np.pi * (kc / n_total))
+        assert rel_l2(y[0], ref) < TOL[dtype], (n_total, c0)
+    with pytest.raises(fa.MfftError):
+        fa.ColumnPlan(n, inner, dtype=dtype, twiddle=(1 << 41, 0))
     # shapes the tile passes do not serve are refused, not mis-computed
     for n, inner in ((8, 64), (48, 64), (64, 8), (64, 48)):
         with pytest.raises(fa.MfftError):
