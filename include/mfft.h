@@ -103,7 +103,7 @@ int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, 
  * inner: a power of two >= 32 (complex64) / 16 (complex128); other shapes return
  * MFFT_E_UNSUPPORTED (callers fall back to mfft_transpose + mfft_plan_1d).  Plain complex in
  * and out, executed with mfft_exec (scale must be 1) or mfft_exec_host.
- * twiddle_n > 0 (a power of two) additionally multiplies output element (k, c) by
+ * twiddle_n > 0 (a power of two, at most 2^40) additionally multiplies output element (k, c) by
  * exp(-2*pi*i * k*(twiddle_c0 + c) / twiddle_n): the inter-step twiddle of the four-step
  * algorithm, folded into the last pass' store. */
 int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
