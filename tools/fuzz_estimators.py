@@ -6,7 +6,8 @@ random N0 / dt / pad, every keyword of fft_from_timeseries (final2.py:115-127) a
 fft_extract_E_p (streamlit_app_combined.py:190) at random values, single and batched calls.
 Mismatches are listed at the end (exit status 1); cases in which the reference's own answer flips under
 a 1e-13 perturbation of the input (exact height ties, fits of coincident lines) are listed apart and
-do not count.
+do not count.  Test infrastructure (tests/test_gpu_spectral.py runs a seeded slice of it): the oracle is
+imported as the checker, never by the product.
     python tools/fuzz_estimators.py [FIRST_SEED [LAST_SEED [CASES_PER_SEED]]]"""
 import os
 import sys
