@@ -246,6 +246,15 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
     const int npass = (log2n + maxg - 1) / maxg;
     if (npass > 4) { set_error("length above the four-pass range"); return MFFT_E_UNSUPPORTED; }
     for (int s = 0; s < npass; ++s) out->push_back(log2n / npass + (s < log2n % npass ? 1 : 0));
+    // complex64 column-batched transforms of 2^12..2^16 points: a 256-point last pass (32-column tiles) and the
+    // rest first -- alternated with the balanced split inside one process, us per transform: 16384 x 16384
+    // (BASELINE config 4's column step) 1820 -> 1720-1776, 16384 x 2048 222 -> 210, 8192 x 16384 870 -> 846,
+    // 32768 x 8192 1790 -> 1766, 4096 x 16384 426 -> 415; 512-point passes lose there (128-byte rows).
+    if (log2_inner && !narrow && dtype == MFFT_C64 && log2n >= 12 && log2n <= 16 && !getenv("MFFT_BALANCED_COLUMNS")) {
+        out->clear();
+        out->push_back(log2n - 8);
+        out->push_back(8);
+    }
     for (size_t s = 0; s < out->size(); ++s) {
         const int g = (*out)[s];
         if (g < kTileMinLog2G) { set_error("tile radix too small"); return MFFT_E_UNSUPPORTED; }
