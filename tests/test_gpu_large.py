@@ -332,3 +332,14 @@ def test_device_buffers_are_checked_against_the_plan(fa):
         with pytest.raises(ValueError, match="elements"):
             p.exec(x, s, d_stats=st[:2])
         torch.cuda.synchronize()
+
+
+def test_column_plans_on_random_shapes(fa):
+    """Seeded slice of tools/fuzz_columns.py: column-batched plans of random length / inner extent / batch,
+    with and without the fused twiddle (moduli up to 2^40), against numpy in float64."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_columns as fz
+    del fz.failures[:]
+    assert fz.run(901, 902, 25, verbose=False) >= 45
+    assert not fz.failures, fz.failures[:3]
