@@ -165,3 +165,14 @@ def test_dist_plan_argument_errors():
     finally:
         for c in comms:
             c.close()
+
+
+def test_local_ranks_on_random_shapes():
+    """Seeded slice of tools/fuzz_dist_local.py: random rank counts, power-of-two shapes, chunk counts and
+    precisions through both decompositions, both output layouts / orders, against numpy."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_dist_local as fz
+    del fz.failures[:], fz.refused[:]
+    assert fz.run(701, 702, 20, verbose=False) >= 30
+    assert not fz.failures, fz.failures[:3]
