@@ -133,6 +133,38 @@ def cpu_multicore(x_host, n, budget_s=5.0):
                       f"scipy.fft.fft(workers={cores}) -> re^2+im^2, scipy {scipy.__version__}"}
 
 
+def _direct_bins_1d(x, ks, chunk=1 << 26):
+    """X[k] = sum_j x[j] exp(-2 pi i j k / n) for a few bins, evaluated directly in float64 on the device
+    (exact integer reduction of j*k mod n): the checker of the long transforms' sampled bins."""
+    import torch
+    n = x.numel()
+    out = []
+    for k in ks:
+        acc = torch.zeros((), dtype=torch.complex128, device=x.device)
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            j = torch.arange(lo, hi, dtype=torch.int64, device=x.device)
+            ang = (-2.0 * math.pi) * (((j * int(k)) % n).to(torch.float64) / n)
+            acc = acc + torch.sum(x[lo:hi].to(torch.complex128) * torch.complex(torch.cos(ang), torch.sin(ang)))
+            del j, ang
+        out.append(acc)
+    return torch.stack(out)
+
+
+def _energy(t, chunk=1 << 27):
+    import torch
+    r = torch.view_as_real(t).reshape(-1)
+    return sum(float(torch.sum(r[lo:lo + chunk].double() ** 2).item()) for lo in range(0, r.numel(), chunk))
+
+
+def _check_1d(x, y, ks):
+    """max |y[k] - X[k]| over the sampled bins, relative to the root-mean-square bin magnitude"""
+    import torch
+    got = y[torch.tensor(ks, device=y.device)].to(torch.complex128)
+    want = _direct_bins_1d(x, ks)
+    return float(torch.max(torch.abs(got - want)).item()) / math.sqrt(_energy(x))
+
+
 def secondary_configs(with_cpu):
     """Short single-GPU timings of the other BASELINE configurations (parity-test cases, not the
     headline): config 3 (2^24 complex64), config 4 (16384^2 complex64 through the slab
@@ -172,7 +204,8 @@ def secondary_configs(with_cpu):
         y = torch.empty_like(x)
         plan = fft_amd.Plan(n, dtype=fft_amd.C64)
         t = timed(lambda: plan.exec(x, y, stream=stream), 30)
-        extra = {"launches": plan.launches}
+        extra = {"launches": plan.launches,
+                 "verified_max_err_over_rms": _check_1d(x, y, [0, 1, 255, 65536, n // 2, n - 1, 12345678 % n]), "verified_bins": 7}
         if with_cpu:
             xh = x.cpu().numpy()
             t0 = time.perf_counter()
@@ -188,7 +221,22 @@ def secondary_configs(with_cpu):
         n = 16384
         a = torch.view_as_complex(torch.randn((n * n, 2), dtype=torch.float32, device="cuda"))
         t = timed(lambda: fd.fft2_slab(a, n, n, comm, ops, restore_layout=True), 3)
-        out["config4_2d_16384x16384_c64_one_gpu"] = entry(t, n * n, 28, 8, local_passes=3)
+        f = fd.fft2_slab(a, n, n, comm, ops, restore_layout=True).view(n, n)
+        a2 = a.view(n, n)
+        j = torch.arange(n, dtype=torch.int64, device="cuda")
+        worst = 0.0
+        bins = [(0, 0), (1, 0), (0, 1), (127, 128), (8191, 8192), (16383, 16383), (12345, 6789)]
+        for k0, k1 in bins:
+            w1 = torch.exp(-2j * math.pi * ((j * k1) % n).double() / n)
+            w0 = torch.exp(-2j * math.pi * ((j * k0) % n).double() / n)
+            acc = torch.zeros((), dtype=torch.complex128, device="cuda")
+            for lo in range(0, n, 2048):
+                acc = acc + torch.dot(w0[lo:lo + 2048], a2[lo:lo + 2048].to(torch.complex128) @ w1)
+            worst = max(worst, abs(complex(f[k0, k1].item()) - complex(acc.item())))
+        out["config4_2d_16384x16384_c64_one_gpu"] = entry(t, n * n, 28, 8, local_passes=3,
+                                                         verified_max_err_over_rms=worst / math.sqrt(_energy(a)),
+                                                         verified_bins=len(bins))
+        del f, a2
         del a
     except Exception as exc:                                  # noqa: BLE001
         out["config4_2d_16384x16384_c64_one_gpu"] = {"error": repr(exc)[:200]}
@@ -205,8 +253,14 @@ def secondary_configs(with_cpu):
             for lo in range(0, n1 * n2, 1 << 27):
                 xr[lo:lo + (1 << 27)].normal_()
             t = timed(lambda: fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True), 1)
+            nn = n1 * n2
+            ks = [0, 1, n1 - 1, n1, nn // 2, nn - 1, 1234567891 % nn]
+            yv = fd.fft1d_fourstep(x, n1, n2, comm, ops, natural_order=True)
+            err = _check_1d(x, yv, ks)
+            del yv
             out[f"config5_1d_2pow{lg}_c128_one_gpu"] = entry(t, n1 * n2, lg, 16, local_passes=5,
-                                                              route="four-step decomposition, one rank")
+                                                              route="four-step decomposition, one rank",
+                                                              verified_max_err_over_rms=err, verified_bins=len(ks))
             ops.close()
             torch.cuda.empty_cache()
             if lg == top:
@@ -215,7 +269,9 @@ def secondary_configs(with_cpu):
                 y = torch.empty_like(x)
                 plan = fft_amd.Plan(n1 * n2, dtype=fft_amd.C128)
                 t = timed(lambda: plan.exec(x, y, stream=stream), 1)
-                out[f"config5_1d_2pow{lg}_c128_one_gpu_single_plan"] = entry(t, n1 * n2, lg, 16, launches=plan.launches)
+                out[f"config5_1d_2pow{lg}_c128_one_gpu_single_plan"] = entry(
+                    t, n1 * n2, lg, 16, launches=plan.launches,
+                    verified_max_err_over_rms=_check_1d(x, y, [0, 1, 255, 65536, nn // 2, nn - 1, 987654321 % nn]), verified_bins=7)
                 plan.destroy()
                 del y
             del x, xr
