@@ -34,6 +34,10 @@
 #define MFFT_TILE_VEC 1      // packed-form butterflies (fft_core.h) in the tile passes: +2..7 % on complex64 2^16..2^27 (0 = scalar form)
 #endif
 
+#ifndef MFFT_TILE_EVAL_ROOTS
+#define MFFT_TILE_EVAL_ROOTS 0 // 1: every tile kernel evaluates its inter-pass roots instead of reading the two-level tables
+#endif
+
 #ifndef MFFT_TILE_PREFETCH
 #define MFFT_TILE_PREFETCH 1 // complex128 512-point tiles (one resident workgroup per CU): next tile's loads issued behind the first butterflies
 #endif
@@ -405,7 +409,7 @@ fft_tile_kernel(const TArgs<T> a)
             }
 #if !MFFT_DIAG_NOFFT
             cx<double> w, step;
-            if constexpr (PF) {
+            if constexpr (PF || MFFT_TILE_EVAL_ROOTS != 0) {
                 // evaluated, not read: table loads issued here would retire behind the previous trip's
                 // stores (the counter is in order), i.e. drain them, and prefetched entries cost sixteen
                 // registers these kernels do not have
