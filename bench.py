@@ -465,8 +465,56 @@ def dist_configs(args, world, rank, c_abi=False):
     return out
 
 
+class _Reporter:
+    """Keeps rank 0's one JSON line safe from the process that measures it.  A child forked before anything
+    touches the GPU reads versions of the line from a pipe and writes the latest complete one to stdout when
+    the pipe closes: after the final version, or when the parent dies inside one of the sharded-transform legs
+    that follow the headline (a GPU fault or an abort in a collective cannot be caught in Python)."""
+
+    def __init__(self):
+        import signal
+        rd, wr = os.pipe()
+        sys.stdout.flush()
+        pid = os.fork()
+        if pid == 0:
+            try:
+                os.close(wr)
+                for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                    signal.signal(sig, signal.SIG_IGN)          # the launcher ends its workers with these
+                buf = b""
+                while True:
+                    chunk = os.read(rd, 1 << 16)
+                    if not chunk:
+                        break
+                    buf += chunk
+                    cut = buf.rfind(b"\n", 0, buf.rfind(b"\n"))  # keep the last complete line and the open tail
+                    if cut >= 0:
+                        buf = buf[cut + 1:]
+                done = buf[:buf.rfind(b"\n") + 1]
+                if done:
+                    os.write(1, done)
+            finally:
+                os._exit(0)
+        os.close(rd)
+        self._wr, self._pid = wr, pid
+
+    def update(self, line):
+        data = (json.dumps(line) + "\n").encode()
+        while data:
+            data = data[os.write(self._wr, data):]
+
+    def close(self):
+        os.close(self._wr)
+        os.waitpid(self._pid, 0)
+
+
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    # several ranks (or the one-rank plumbing check of the sharded legs): rank 0 hands its line to a reporter
+    reporter = None
+    if int(os.environ.get("RANK", "0")) == 0 and (world_env > 1 or args.dist_configs) and not args.no_dist_configs:
+        reporter = _Reporter()
     import numpy as np
     import torch
     import fft_amd
@@ -597,8 +645,12 @@ def main():
             def abandon():
                 if rank == 0:
                     line[key] = {"error": f"abandoned after {seconds:.0f} s"}
-                    print(json.dumps(line), flush=True)
+                    reporter.update(line)
+                    reporter.close()
                 os._exit(0)
+            if rank == 0:
+                line[key] = {"error": "the process ended inside this leg"}    # what is printed if it does
+                reporter.update(line)
             timer = threading.Timer(seconds, abandon)
             timer.daemon = True
             timer.start()
@@ -616,7 +668,11 @@ def main():
             # on several in-process ranks only).
             fenced("dist_configs_c_abi", args.c_abi_timeout, lambda: dist_configs(args, world, rank, c_abi=True))
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        if reporter is not None:
+            reporter.update(line)
+            reporter.close()
+        else:
+            print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -205,3 +205,30 @@ def test_batch_weights_match_one_fit_per_block():
         r = gram[b, 2 * want * want:-1].view(np.complex128)
         _, p, _ = _solve_normal(G, r, float(gram[b, -1]), np.arange(k))
         np.testing.assert_allclose(w[b], p, rtol=0, atol=1e-12)
+
+
+def test_bench_reporter_prints_the_latest_complete_line_once(tmp_path):
+    """bench.py's rank 0 hands its JSON line to a child forked before the GPU is touched; the child prints
+    the latest complete version when the pipe closes -- on a normal end and when the parent is killed."""
+    import json, subprocess, sys, textwrap
+    script = tmp_path / "rep.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, signal, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        r = bench._Reporter()
+        r.update({{"a": 1}})
+        r.update({{"a": 2, "big": "x" * 300000}})
+        if sys.argv[1] == "kill":
+            os.write(r._wr, b'{{"a": 3, "half')
+            os.kill(os.getpid(), signal.SIGKILL)
+        if sys.argv[1] == "abort":
+            os.abort()
+        r.update({{"a": 4}})
+        r.close()
+    """))
+    for mode, want in (("kill", 2), ("abort", 2), ("ok", 4)):
+        out = subprocess.run([sys.executable, str(script), mode], capture_output=True, timeout=60).stdout.decode()
+        lines = [l for l in out.split("\n") if l]
+        assert len(lines) == 1, (mode, len(lines))
+        assert json.loads(lines[0])["a"] == want, mode
