@@ -35,7 +35,9 @@
 #endif
 
 #ifndef MFFT_TILE_EVAL_ROOTS
-#define MFFT_TILE_EVAL_ROOTS 0 // 1: every tile kernel evaluates its inter-pass roots instead of reading the two-level tables
+#define MFFT_TILE_EVAL_ROOTS 2 // inter-pass roots evaluated per thread instead of read from the two-level tables: 0 only in the
+                               // prefetching kernels, 1 in every tile kernel, 2 also in the complex64 512-point tiles
+                               // (2^18: +7 %, 2^19: +4 %, 2^26: +5 %, 2^27: +11 %; all other kernels measured neutral)
 #endif
 
 #ifndef MFFT_TILE_PREFETCH
@@ -409,7 +411,7 @@ fft_tile_kernel(const TArgs<T> a)
             }
 #if !MFFT_DIAG_NOFFT
             cx<double> w, step;
-            if constexpr (PF || MFFT_TILE_EVAL_ROOTS != 0) {
+            if constexpr (PF || MFFT_TILE_EVAL_ROOTS == 1 || (MFFT_TILE_EVAL_ROOTS == 2 && sizeof(T) == 4 && LOG2G >= 9)) {
                 // evaluated, not read: table loads issued here would retire behind the previous trip's
                 // stores (the counter is in order), i.e. drain them, and prefetched entries cost sixteen
                 // registers these kernels do not have
