@@ -40,6 +40,45 @@ def test_prefetching_512_point_tiles_against_numpy(fa, monkeypatch, split, log2n
     assert rel_l2(y, so.dft(x, engine="numpy")) < TOL[1]
 
 
+@pytest.mark.parametrize("split,log2n,batch", [("9,9", 18, 5), ("10,9", 19, 3), ("9,9,4", 22, 1), ("4,9,9", 22, 2), ("5,9,9", 23, 1)])
+def test_complex64_512_point_tiles_with_evaluated_roots(fa, monkeypatch, split, log2n, batch):
+    """The complex64 512-point tile passes evaluate their inter-pass roots per thread (every other complex64
+    tile reads the two-level tables): as last pass of two- and three-pass plans and as middle pass, all
+    bins against the oracle's engine."""
+    monkeypatch.setenv("MFFT_SPLIT", split)
+    n = 1 << log2n
+    x = _rand((batch, n), 99 + log2n + batch, np.complex64)
+    with fa.Plan(n, batch=batch, dtype=0) as p:
+        assert p.launches == len(split.split(","))
+        y = p.exec_host(x)
+    assert rel_l2(y, so.dft(x, engine="numpy")) < TOL[0]
+
+
+def test_large_complex64_plans_on_sampled_bins(fa):
+    """2^26 and 2^27 complex64 points (9,9,8 and 9,9,9: one and two twiddled 512-point passes): sampled bins
+    against the DFT evaluated directly in float64, and Parseval."""
+    import math
+    import torch
+    from test_gpu_fullsize import _direct_bins_1d, _energy
+    torch.cuda.set_device(0)
+    for lg in (26, 27):
+        n = 1 << lg
+        g = torch.Generator(device="cuda").manual_seed(lg)
+        x = torch.empty(n, dtype=torch.complex64, device="cuda")
+        torch.view_as_real(x).normal_(generator=g)
+        y = torch.empty_like(x)
+        with fa.Plan(n, dtype=fa.C64) as p:
+            assert p.launches == 3
+            p.exec(x, y, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        e_in = _energy(x)
+        assert abs(_energy(y) / (n * e_in) - 1.0) < 1e-5
+        ks = [0, 1, 511, 512, 513, n // 2 - 1, n // 2, n - 512, n - 1, 123456789 % n, 98765432 % n]
+        got = y[torch.tensor(ks, device="cuda")].cpu().numpy()
+        want = _direct_bins_1d(x, ks)
+        assert np.max(np.abs(got - want)) / math.sqrt(e_in) < 2e-6, lg
+
+
 def test_large_complex128_plans_on_sampled_bins(fa):
     """2^25 .. 2^27 complex128 points (512-point first / middle / last passes as the library itself picks
     them): sampled bins against the DFT evaluated directly in float64, and Parseval."""
