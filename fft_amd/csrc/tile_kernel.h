@@ -40,6 +40,11 @@
                                // (2^18: +7 %, 2^19: +4 %, 2^26: +5 %, 2^27: +11 %; all other kernels measured neutral)
 #endif
 
+#ifndef MFFT_TILE_PF_POWER
+#define MFFT_TILE_PF_POWER 1 // the power-spectrum last pass of the 512-point complex128 tiles prefetches too (252 registers, no
+                             // scratch; 2^18: +5 %, 2^19: +2 %, 2^27: +6 %, with statistics +1.5-2 %; other lengths unchanged)
+#endif
+
 #ifndef MFFT_TILE_PREFETCH
 #define MFFT_TILE_PREFETCH 1 // complex128 512-point tiles (one resident workgroup per CU): next tile's loads issued behind the first butterflies
 #endif
@@ -264,7 +269,8 @@ fft_tile_kernel(const TArgs<T> a)
     // and the stores.  For that the barriers of the exchanges must not drain the vector-memory counter
     // (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
     // (tile_root) instead of read from the tables.
-    constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
+    constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
+                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER);
     // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
     // pass -6 %, middle passes +6 % -- and keep the plain loop.)
     constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
@@ -568,9 +574,10 @@ fft_tile_kernel(const TArgs<T> a)
             }
         } else {
             double mx = 0.0, sm = 0.0, sk = 0.0;
-            int64_t kk[P];
-#pragma unroll
-            for (int e = 0; e < P; ++e) kk[e] = j + (int64_t)(t + TX * e) * a.NS;
+            // output bin of v[e]: k = j + (t + TX*e) * NS, formed where it is used (an array of them costs
+            // 2 P registers the prefetching kernels do not have)
+            const int64_t kk0 = j + (int64_t)t * a.NS, kkstep = (int64_t)TX * a.NS;
+            const auto kk = [&](int e) { return kk0 + e * kkstep; };
 #pragma unroll
             for (int e = 0; e < P; ++e) { v[e].x *= a.scale; v[e].y *= a.scale; }
             if (a.conj_out) {
@@ -579,14 +586,14 @@ fft_tile_kernel(const TArgs<T> a)
             }
             if (a.post) {
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.post[kk[e] < a.n_out ? kk[e] : a.n_out - 1]);
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.post[kk(e) < a.n_out ? kk(e) : a.n_out - 1]);
             }
             const int64_t obase = b * a.out_stride;
             if constexpr (MODE == TM_LAST_POWER) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
                     const T s = v[e].x * v[e].x + v[e].y * v[e].y;
-                    const int64_t k = kk[e];
+                    const int64_t k = kk(e);
                     if (k < a.n_out) {
                         reinterpret_cast<T*>(a.out)[obase + seg_index(k, a.out_seg, a.out_seg_stride)] = s;
                         const double f = (k < (a.n_out + 1) / 2) ? (double)k : (double)(k - a.n_out);
@@ -598,8 +605,8 @@ fft_tile_kernel(const TArgs<T> a)
             } else {
 #pragma unroll
                 for (int e = 0; e < P; ++e) {
-                    if (kk[e] < a.n_out)
-                        reinterpret_cast<C_*>(a.out)[obase + seg_index(kk[e], a.out_seg, a.out_seg_stride)] = v[e];
+                    if (kk(e) < a.n_out)
+                        reinterpret_cast<C_*>(a.out)[obase + seg_index(kk(e), a.out_seg, a.out_seg_stride)] = v[e];
                 }
             }
             if constexpr (MODE == TM_LAST_POWER) {

@@ -54,6 +54,29 @@ def test_complex64_512_point_tiles_with_evaluated_roots(fa, monkeypatch, split, 
     assert rel_l2(y, so.dft(x, engine="numpy")) < TOL[0]
 
 
+@pytest.mark.parametrize("split,log2n,batch,stats", [("9,9", 18, 24, True), ("9,9", 18, 17, False), ("9,4,9", 22, 1, True),
+                                                     ("5,9,9", 23, 1, False), ("10,9", 19, 9, True)])
+def test_prefetching_power_last_pass_against_numpy(fa, monkeypatch, split, log2n, batch, stats):
+    """The power-spectrum last pass of the 512-point complex128 tiles prefetches like the plain passes: one to
+    four trips per workgroup (odd and even counts, batches that end inside a sweep), with and without the
+    statistics, every bin and the three statistics against numpy."""
+    monkeypatch.setenv("MFFT_SPLIT", split)
+    n = 1 << log2n
+    x = _rand((batch, n), 55 + log2n + batch, np.complex128)
+    flags = fa.POWER | (fa.STATS if stats else 0)
+    with fa.Plan(n, batch=batch, dtype=1, flags=flags) as p:
+        assert p.launches >= len(split.split(","))          # the statistics add their reduction
+        res = p.exec_host(x, scale=0.5)
+    S, st = res if stats else (res, None)
+    ref = np.abs(0.5 * np.fft.fft(x, axis=-1)) ** 2
+    assert rel_l2(S, ref) < 1e-13
+    if stats:
+        f = np.fft.fftfreq(n) * n
+        assert np.max(np.abs(st[:, 0] - ref.max(axis=1)) / ref.max(axis=1)) < 1e-12
+        assert np.max(np.abs(st[:, 1] - ref.sum(axis=1)) / ref.sum(axis=1)) < 1e-12
+        assert np.max(np.abs(st[:, 2] - (ref * f).sum(axis=1)) / np.abs(ref * f).sum(axis=1)) < 1e-11
+
+
 def test_large_complex64_plans_on_sampled_bins(fa):
     """2^26 and 2^27 complex64 points (9,9,8 and 9,9,9: one and two twiddled 512-point passes): sampled bins
     against the DFT evaluated directly in float64, and Parseval."""
