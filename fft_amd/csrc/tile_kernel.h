@@ -40,6 +40,10 @@
                                // (2^18: +7 %, 2^19: +4 %, 2^26: +5 %, 2^27: +11 %; all other kernels measured neutral)
 #endif
 
+#ifndef MFFT_TILE_PF_GEN
+#define MFFT_TILE_PF_GEN 0 // 1: so does their last pass with the general epilogue (scale, conjugate, table, segmented rows)
+#endif
+
 #ifndef MFFT_TILE_PF_POWER
 #define MFFT_TILE_PF_POWER 1 // the power-spectrum last pass of the 512-point complex128 tiles prefetches too (252 registers, no
                              // scratch; 2^18: +5 %, 2^19: +2 %, 2^27: +6 %, with statistics +1.5-2 %; other lengths unchanged)
@@ -270,7 +274,7 @@ fft_tile_kernel(const TArgs<T> a)
     // (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
     // (tile_root) instead of read from the tables.
     constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
-                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER);
+                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER) || (MFFT_TILE_PF_GEN != 0 && MODE == TM_LAST_GEN);
     // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
     // pass -6 %, middle passes +6 % -- and keep the plain loop.)
     constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
