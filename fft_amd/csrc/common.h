@@ -124,5 +124,6 @@ int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s);
 int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s);
 int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class
 int tile_log2c_c128(int log2g, int narrow);
+bool tile_first_hann_c128(int log2g);         // is there a first pass that evaluates the Hann window (TM_FIRST_HANN) at this radix?
 
 }  // namespace mfft

@@ -40,6 +40,11 @@
                                // (2^18: +7 %, 2^19: +4 %, 2^26: +5 %, 2^27: +11 %; all other kernels measured neutral)
 #endif
 
+#ifndef MFFT_TILE_PF_HANN
+#define MFFT_TILE_PF_HANN 1 // the first pass of a Hann-windowed (and zero-padded) complex128 transform whose tiles are 512 points
+                            // prefetches too, evaluating the window per thread (TM_FIRST_HANN) instead of reading its table
+#endif
+
 #ifndef MFFT_TILE_PF_GEN
 #define MFFT_TILE_PF_GEN 0 // 1: so does their last pass with the general epilogue (scale, conjugate, table, segmented rows)
 #endif
@@ -114,6 +119,9 @@ template <typename T> struct TArgs {
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
     T scale;
+    // FIRST_HANN: the window 0.5 - 0.5 cos(2 pi i / (n_in - 1)) is evaluated from the turn fraction i * win_inv_m;
+    // win_step = ((TX * L) mod (n_in - 1)) / (n_in - 1), the fraction between a thread's consecutive samples
+    double win_inv_m, win_step;
 };
 
 // sin and cos of |theta| <= pi/4 in double: Taylor polynomials through theta^15 / theta^16 (truncation
@@ -165,11 +173,26 @@ __device__ __forceinline__ cx<double> tile_root(uint64_t k, int log2n)      // n
     return cx<double>{c, -sn};
 }
 
+// (cos, sin) of 2*pi*f for a turn fraction 0 <= f <= 1 (nearest quarter turn, remainder through sincos_eighth)
+__device__ __forceinline__ cx<double> tile_turn(double f)
+{
+    const double q = rint(4.0 * f);
+    double sa, ca;
+    sincos_eighth(6.283185307179586 * fma(-0.25, q, f), &sa, &ca);
+    switch ((int)q & 3) {
+    case 0: return cx<double>{ca, sa};
+    case 1: return cx<double>{-sa, ca};
+    case 2: return cx<double>{-ca, -sa};
+    default: return cx<double>{sa, -ca};
+    }
+}
+
 // MID: plain strided in / strided out.  FIRST_*: sample order in, contiguous runs out, no
 // inter-pass twiddle.  LAST_*: natural-order bins out.  *_PLAIN = dense full-length complex
 // data and nothing fused; *_GEN / LAST_POWER carry the runtime prologue / epilogue.
 enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN = 3, TM_LAST_GEN = 4,
-                TM_LAST_POWER = 5, TM_LAST_TWID = 6 };
+                TM_LAST_POWER = 5, TM_LAST_TWID = 6,
+                TM_FIRST_HANN = 7 };   // dense complex input of n_in <= N samples, Hann window evaluated, zero padding (prefetching tiles only)
 
 // Columns per tile.  Wide (default): 512-byte rows where LDS allows -- 64 complex64 columns up to
 // 128-point tiles, 32 at 256 points, 16 at 512; 32 complex128 columns up to 256 points, 16 at 512.
@@ -254,7 +277,7 @@ template <typename T, int LOG2G, int LOG2C, int MODE>
 __global__ void __launch_bounds__(((TileCfg<LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<LOG2G>::TX) << LOG2C), MODE>()))
 fft_tile_kernel(const TArgs<T> a)
 {
-    constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN);
+    constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN || MODE == TM_FIRST_HANN);
     using C_ = cx<T>;
     using TC = TileCfg<LOG2G>;
     using RD = typename TC::SC::RD;
@@ -274,7 +297,8 @@ fft_tile_kernel(const TArgs<T> a)
     // (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
     // (tile_root) instead of read from the tables.
     constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
-                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER) || (MFFT_TILE_PF_GEN != 0 && MODE == TM_LAST_GEN);
+                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER) || (MFFT_TILE_PF_GEN != 0 && MODE == TM_LAST_GEN) ||
+                              MODE == TM_FIRST_HANN;
     // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
     // pass -6 %, middle passes +6 % -- and keep the plain loop.)
     constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
@@ -307,7 +331,16 @@ fft_tile_kernel(const TArgs<T> a)
         const C_* __restrict__ p = reinterpret_cast<const C_*>(a.in) + b * a.in_stride + j0 +
                                    ((uint32_t)c + (uint32_t)t * (uint32_t)a.L);
         const int64_t pstep = (int64_t)TX * a.L;
-        if (a.nt & 1) {
+        if constexpr (MODE == TM_FIRST_HANN) {
+            // n_in <= N samples per signal: indices past the last sample read that sample (zeroed in the trip)
+            const C_* __restrict__ sig = reinterpret_cast<const C_*>(a.in) + b * a.in_stride;
+            const int64_t i0 = j0 + ((uint32_t)c + (uint32_t)t * (uint32_t)a.L), last = a.n_in - 1;
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const int64_t i = i0 + e * pstep;
+                dst[e] = tile_ld<T, false>(sig + (i < last ? i : last));
+            }
+        } else if (a.nt & 1) {
 #pragma unroll
             for (int e = 0; e < P; ++e) { dst[e] = tile_ld<T, true>(p); p += pstep; }
         } else {
@@ -358,6 +391,22 @@ fft_tile_kernel(const TArgs<T> a)
 #pragma unroll
                     for (int e = 0; e < P; ++e) { v[e] = tile_ld<T, false>(p); p += pstep; }
                 }
+            }
+        } else if constexpr (MODE == TM_FIRST_HANN) {
+            static_assert(MODE != TM_FIRST_HANN || PF, "the evaluated-window first pass exists for the prefetching tiles only");
+            // samples requested above / by the previous trip.  Window of sample i = i0 + e*pstep: the point
+            // exp(2 pi i * i/(n_in - 1)) is stepped along the thread's constant stride (double recurrence, P steps)
+            const int64_t i0 = j + (int64_t)t * a.L;
+            cx<double> z = tile_turn((double)(i0 < a.n_in ? i0 : 0) * a.win_inv_m);
+            double ws = a.win_step;
+            asm volatile("" : "+v"(ws));       // evaluated per trip: hoisted out of the loop the step costs four registers for its whole length
+            const cx<double> zs = tile_turn(ws);
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                const double wv = (i0 + e * pstep < a.n_in) ? fma(-0.5, z.x, 0.5) : 0.0;    // zero padding
+                v[e].x = (T)((double)v[e].x * wv);
+                v[e].y = (T)((double)v[e].y * wv);
+                z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};
             }
         } else if constexpr (MODE == TM_FIRST_GEN) {
             // runtime prologue: unconditional loads at clamped indices, options as uniform
@@ -691,6 +740,12 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
     return MFFT_OK;
 }
 
+// which tiles have the evaluated-window first pass: the prefetching ones (512-point complex128)
+template <typename T, int LOG2G> constexpr bool tile_first_hann()
+{
+    return MFFT_TILE_PF_HANN != 0 && MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && LOG2G == 9;
+}
+
 template <typename T, int LOG2G>
 int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
 {
@@ -714,6 +769,17 @@ int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
     case TM_LAST_GEN: return launch_tile_one<T, LOG2G, LC, TM_LAST_GEN>(a, s);
     case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LC, TM_LAST_POWER>(a, s);
     case TM_LAST_TWID: return launch_tile_one<T, LOG2G, LC, TM_LAST_TWID>(a, s);
+    case TM_FIRST_HANN:
+        if constexpr (tile_first_hann<T, LOG2G>()) {
+            if (a.n_in < 2) break;
+            TArgs<T> h = a;
+            const int64_t m = a.n_in - 1;
+            h.win_inv_m = (double)(1.0L / (long double)m);
+            h.win_step = (double)((long double)(((int64_t)TileCfg<LOG2G>::TX * a.L) % m) / (long double)m);
+            return launch_tile_one<T, LOG2G, LC, TM_FIRST_HANN>(h, s);
+        } else {
+            break;
+        }
     }
     set_error("unknown tile mode");
     return MFFT_E_INVALID;

@@ -77,6 +77,32 @@ def test_prefetching_power_last_pass_against_numpy(fa, monkeypatch, split, log2n
         assert np.max(np.abs(st[:, 2] - (ref * f).sum(axis=1)) / np.abs(ref * f).sum(axis=1)) < 1e-11
 
 
+@pytest.mark.parametrize("split,log2n,batch,n_in,power", [
+    ("9,9", 18, 3, 1 << 18, False), ("9,9", 18, 24, 200001, True), ("9,9", 18, 17, 131072, False), ("9,9", 18, 2, 2, False),
+    ("9,9", 18, 2, 3, True), ("9,9", 18, 5, 513, False), ("9,9", 18, 5, (1 << 18) - 1, True), ("9,8", 17, 40, 100000, True),
+    ("9,9,4", 22, 1, 3000001, True), ("9,4,9", 22, 2, 1 << 21, False)])
+def test_first_pass_with_evaluated_hann_window_against_numpy(fa, monkeypatch, split, log2n, batch, n_in, power):
+    """np.fft.fft(x * np.hanning(n_in), n) (final2.py:139-143) where the first pass is a prefetching 512-point
+    complex128 tile: the window is evaluated per thread instead of read from its table, samples past n_in are
+    clamped loads turned into zeros.  Full and padded lengths, odd and tiny sample counts (np.hanning(2) is
+    all zeros), one to several trips per workgroup; and the table route gives the same spectrum."""
+    monkeypatch.setenv("MFFT_SPLIT", split)
+    n = 1 << log2n
+    x = _rand((batch, n_in), 31 + log2n + batch, np.complex128)
+    flags = fa.HANN | (fa.POWER if power else 0)
+    ref = np.fft.fft(x * np.hanning(n_in), n, axis=-1)
+    if power:
+        ref = np.abs(ref) ** 2
+    with fa.Plan(n, n_in=n_in, batch=batch, dtype=1, flags=flags) as p:
+        y = p.exec_host(x)
+        monkeypatch.setenv("MFFT_TABLE_WINDOW", "1")
+        yt = p.exec_host(x)
+    if np.any(ref):
+        assert rel_l2(y, ref) < 1e-13 and rel_l2(yt, ref) < 1e-13
+    else:
+        assert not np.any(y) and not np.any(yt)
+
+
 def test_large_complex64_plans_on_sampled_bins(fa):
     """2^26 and 2^27 complex64 points (9,9,8 and 9,9,9: one and two twiddled 512-point passes): sampled bins
     against the DFT evaluated directly in float64, and Parseval."""
