@@ -540,10 +540,10 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         const bool in_plain = !io.win && !io.pre && !io.real_in && !io.conj_in && io.n_in == n && io.in_seg == 0;
         const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 &&
                                io.scale == (T)1 && !io.power;
-        // dense complex samples under the Hann window (zero-padded or not) into prefetching tiles: window evaluated
+        // dense complex samples under the Hann window and / or zero-padded into prefetching tiles: window evaluated
         bool in_hann = false;
         if constexpr (sizeof(T) == 8)
-            in_hann = io.win && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
+            in_hann = (io.win || io.n_in < n) && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
                       inner == 1 && !narrow && tile_first_hann_c128(gp.log2g) && !getenv("MFFT_TABLE_WINDOW");
         int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : TM_FIRST_GEN))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);

@@ -403,7 +403,7 @@ fft_tile_kernel(const TArgs<T> a)
             const cx<double> zs = tile_turn(ws);
 #pragma unroll
             for (int e = 0; e < P; ++e) {
-                const double wv = (i0 + e * pstep < a.n_in) ? fma(-0.5, z.x, 0.5) : 0.0;    // zero padding
+                const double wv = (i0 + e * pstep < a.n_in) ? (a.win ? fma(-0.5, z.x, 0.5) : 1.0) : 0.0;    // zero padding
                 v[e].x = (T)((double)v[e].x * wv);
                 v[e].y = (T)((double)v[e].y * wv);
                 z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};

@@ -97,10 +97,17 @@ def test_first_pass_with_evaluated_hann_window_against_numpy(fa, monkeypatch, sp
         y = p.exec_host(x)
         monkeypatch.setenv("MFFT_TABLE_WINDOW", "1")
         yt = p.exec_host(x)
+        monkeypatch.delenv("MFFT_TABLE_WINDOW")
     if np.any(ref):
         assert rel_l2(y, ref) < 1e-13 and rel_l2(yt, ref) < 1e-13
     else:
         assert not np.any(y) and not np.any(yt)
+    if n_in < n:
+        # the same pass serves zero padding without a window: np.fft.fft(x, n)
+        with fa.Plan(n, n_in=n_in, batch=batch, dtype=1, flags=fa.POWER if power else 0) as p:
+            y = p.exec_host(x)
+        ref = np.fft.fft(x, n, axis=-1)
+        assert rel_l2(y, np.abs(ref) ** 2 if power else ref) < 1e-13
 
 
 def test_large_complex64_plans_on_sampled_bins(fa):
