@@ -196,6 +196,7 @@ struct Pow2Engine {
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
     int narrow = 0;                     // tile width class (TileCols)
+    bool table_window = false;          // MFFT_TABLE_WINDOW at build: windowed first passes read the window table (tuning aid)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
 
@@ -281,6 +282,7 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
 {
     n = n_; batch = batch_; dtype = dtype_; inner = inner_; fs_n = fs_n_; fs_c0 = fs_c0_;
     log2n = ilog2(n);
+    table_window = getenv("MFFT_TABLE_WINDOW") != nullptr;
     if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
     if (!is_pow2(inner)) { set_error("the inner extent of a column-batched transform must be a power of two"); return MFFT_E_UNSUPPORTED; }
     const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
@@ -544,7 +546,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         bool in_hann = false;
         if constexpr (sizeof(T) == 8)
             in_hann = (io.win || io.n_in < n) && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
-                      inner == 1 && !narrow && tile_first_hann_c128(gp.log2g) && !getenv("MFFT_TABLE_WINDOW");
+                      inner == 1 && !narrow && tile_first_hann_c128(gp.log2g) && !table_window;
         int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : TM_FIRST_GEN))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
         if (inner > 1) {
