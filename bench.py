@@ -3,8 +3,13 @@
 65536 signals, fused Hann window + power spectrum, per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (starts N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`--gpus N` without a launcher's WORLD_SIZE in the environment starts the N ranks as fresh child
+processes (torch.distributed.run on 127.0.0.1) before this process makes any GPU call, relays
+rank 0's line and returns the children's status; `--gpus` that disagrees with WORLD_SIZE is refused.
 
 One step = one pass of the hot path over one batch (already resident in HBM).
 With N > 1 every rank transforms its own batch of 65536 signals (independent
@@ -33,9 +38,11 @@ BATCH = 65536
 DT = 0.01
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of the job, one per GPU (default: the launcher's WORLD_SIZE, else 1); "
+                         "N > 1 without a launcher starts N ranks")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--settle", type=float, default=1.5,
@@ -65,7 +72,102 @@ def parse():
                     help="log2 length of the sharded 1-D transform (config 5); 0 = 31 on 8 ranks, else 28 + log2(ranks)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="all ranks share cuda:0 (use with --backend gloo on a one-GPU box; not a measurement)")
-    return ap.parse_args()
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="every rank joins the process group, the ranks count themselves with one all-reduce and "
+                         "rank 0 prints a line without a measurement; nothing touches a GPU (checks the launch path)")
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port when this process starts the ranks itself (0 = a free one)")
+    return ap.parse_args(argv)
+
+
+EXIT_REFUSED = 2        # --gpus disagrees with the launcher's WORLD_SIZE
+EXIT_ABANDONED = 3      # a sharded leg did not finish in time: the line is printed, the run was cut short
+
+
+def resolve_world(args, env):
+    """(world size, must this process start the ranks itself?) from --gpus and the launcher's environment.
+    A launcher (torch.distributed.run) sets WORLD_SIZE; --gpus must agree with it when both are given."""
+    env_world = env.get("WORLD_SIZE")
+    if env_world is not None:
+        env_world = int(env_world)
+        if args.gpus is not None and args.gpus != env_world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world} of the launcher; "
+                             "refusing to report a line for a job of another size")
+        return env_world, False
+    gpus = 1 if args.gpus is None else args.gpus
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    return gpus, gpus > 1
+
+
+def launch_ranks(gpus, argv, port=0):
+    """Start `gpus` fresh ranks of this script under torch.distributed.run (rendezvous on 127.0.0.1) and return
+    their status.  Called before this process has imported torch or made any GPU call; the children inherit
+    stdout, so rank 0's single JSON line is this command's output."""
+    import socket
+    import subprocess
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args):
+    """The launch path without a GPU: join the group, count the ranks, rank 0 prints a line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    counted = 1
+    if world > 1:
+        dist.init_process_group(args.backend)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        counted = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "FFT GFLOP/s (5N·log2N) + achieved HBM GB/s vs roofline", "value": None,
+                          "unit": "GFLOP/s", "n_gpus": counted, "steps": args.steps, "warmup": args.warmup,
+                          "rendezvous_only": True, "ranks_counted": counted, "backend": args.backend}), flush=True)
+    return 0
+
+
+def fenced(line, key, seconds, fn, rank, reporter):
+    """Run one sharded leg under a watchdog.  A collective that never returns must not cost the job its
+    headline: when the leg has not finished after `seconds`, rank 0 hands the line with what has been measured
+    to the reporter and every rank leaves with EXIT_ABANDONED, so the launcher and whoever reads the exit
+    status see that the run was cut short."""
+    import threading
+
+    def abandon():
+        if rank == 0:
+            line[key] = {"error": f"abandoned after {seconds:.0f} s"}
+            reporter.update(line)
+            reporter.close()
+        else:
+            time.sleep(2.0)            # the launcher ends the job when the first rank leaves: let rank 0 report
+        os._exit(EXIT_ABANDONED)
+    if rank == 0:
+        line[key] = {"error": "the process ended inside this leg"}    # what is printed if it does
+        reporter.update(line)
+    timer = threading.Timer(seconds, abandon)
+    timer.daemon = True
+    timer.start()
+    try:
+        res = fn()
+    except Exception as exc:                          # noqa: BLE001 - a side measurement
+        res = {"error": repr(exc)[:300]}
+    timer.cancel()
+    if rank == 0:
+        line[key] = res
 
 
 def synth(batch, n, seed):
@@ -508,9 +610,15 @@ class _Reporter:
         os.waitpid(self._pid, 0)
 
 
-def main():
-    args = parse()
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    world_env, spawn = resolve_world(args, os.environ)
+    if spawn:
+        # no launcher: start the ranks as fresh processes; this process never touches a GPU
+        return launch_ranks(world_env, argv, args.master_port)
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     # several ranks (or the one-rank plumbing check of the sharded legs): rank 0 hands its line to a reporter
     reporter = None
     if int(os.environ.get("RANK", "0")) == 0 and (world_env > 1 or args.dist_configs) and not args.no_dist_configs:
@@ -519,7 +627,7 @@ def main():
     import torch
     import fft_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
@@ -586,11 +694,14 @@ def main():
 
     flops_step = 5.0 * n * log2n * batch * world
     alg_bytes = (8 + 4) * n * batch                       # per launch, per GPU
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and n == N_POINTS and batch == BATCH:
         with open(tpath) as fh:
             traffic = json.load(fh).get("bytes_per_launch")
+        traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc passes over this command recorded earlier "
+                          "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch); "
+                          "not collected in this run")
     line = {
         "metric": "FFT GFLOP/s (5N·log2N) + achieved HBM GB/s vs roofline",
         "value": flops_step * args.steps / elapsed / 1e9,
@@ -609,7 +720,7 @@ def main():
                    "n": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kern_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg_bytes / kern_avg_s / 1e9 / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "fft_lds_kernel (hann+power)",
+                     "traffic": traffic, "traffic_source": traffic_source, "kernel": "fft_lds_kernel (hann+power)",
                      "kernel_ms_avg": kern_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
@@ -639,34 +750,12 @@ def main():
         # Both legs are fenced: a collective that never returns must not cost the job its headline.  When a
         # leg has not finished in time every rank leaves, rank 0 after printing the line with what the
         # job has measured so far.
-        import threading
-
-        def fenced(key, seconds, fn):
-            def abandon():
-                if rank == 0:
-                    line[key] = {"error": f"abandoned after {seconds:.0f} s"}
-                    reporter.update(line)
-                    reporter.close()
-                os._exit(0)
-            if rank == 0:
-                line[key] = {"error": "the process ended inside this leg"}    # what is printed if it does
-                reporter.update(line)
-            timer = threading.Timer(seconds, abandon)
-            timer.daemon = True
-            timer.start()
-            try:
-                res = fn()
-            except Exception as exc:                          # noqa: BLE001 - a side measurement
-                res = {"error": repr(exc)[:300]}
-            timer.cancel()
-            if rank == 0:
-                line[key] = res
-
-        fenced("dist_configs", args.dist_timeout, lambda: dist_configs(args, world, rank))
+        fenced(line, "dist_configs", args.dist_timeout, lambda: dist_configs(args, world, rank), rank, reporter)
         if (args.backend == "nccl" or not distributed) and not args.no_dist_c_abi:
             # Same configs through libmfft's own RCCL calls (this route has run on RCCL with one rank and
             # on several in-process ranks only).
-            fenced("dist_configs_c_abi", args.c_abi_timeout, lambda: dist_configs(args, world, rank, c_abi=True))
+            fenced(line, "dist_configs_c_abi", args.c_abi_timeout,
+                   lambda: dist_configs(args, world, rank, c_abi=True), rank, reporter)
     if rank == 0:
         if reporter is not None:
             reporter.update(line)
@@ -675,7 +764,8 @@ def main():
             print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -232,3 +232,76 @@ def test_bench_reporter_prints_the_latest_complete_line_once(tmp_path):
         lines = [l for l in out.split("\n") if l]
         assert len(lines) == 1, (mode, len(lines))
         assert json.loads(lines[0])["a"] == want, mode
+
+
+def _bench_args(*argv):
+    import bench
+    return bench.parse(list(argv))
+
+
+def test_bench_world_size_comes_from_gpus_or_the_launcher():
+    """--gpus N without a launcher means: start N ranks; with a launcher it must agree with WORLD_SIZE."""
+    import bench
+    assert bench.resolve_world(_bench_args(), {}) == (1, False)
+    assert bench.resolve_world(_bench_args("--gpus", "1"), {}) == (1, False)
+    assert bench.resolve_world(_bench_args("--gpus", "8"), {}) == (8, True)
+    assert bench.resolve_world(_bench_args("--gpus", "8"), {"WORLD_SIZE": "8"}) == (8, False)
+    assert bench.resolve_world(_bench_args(), {"WORLD_SIZE": "4"}) == (4, False)
+    for gpus, env in (("8", "1"), ("1", "8"), ("2", "4")):
+        with pytest.raises(SystemExit) as ei:
+            bench.resolve_world(_bench_args("--gpus", gpus), {"WORLD_SIZE": env})
+        assert "disagrees" in str(ei.value.code)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(_bench_args("--gpus", "0"), {})
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two fresh ranks, which find each
+    other and count themselves; rank 0's single line says n_gpus == 2 (no GPU is touched on this route)."""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                           "--rendezvous-only", "--steps", "7", "--warmup", "3"],
+                          capture_output=True, timeout=300, env=env)
+    assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+    lines = [l for l in proc.stdout.decode().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout.decode()
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_counted"] == 2 and line["steps"] == 7 and line["warmup"] == 3
+    # a launcher's WORLD_SIZE that disagrees is refused before anything else happens
+    env2 = dict(env, WORLD_SIZE="4", RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                          capture_output=True, timeout=120, env=env2)
+    assert proc.returncode != 0 and b"disagrees" in proc.stderr and not proc.stdout.strip()
+
+
+def test_bench_abandoned_leg_exits_nonzero_and_still_prints_the_line(tmp_path):
+    """A sharded leg that does not come back: the watchdog hands the line to the reporter and the process
+    leaves with a non-zero status of its own (a launcher must not record the job as a success)."""
+    import json, subprocess, sys, textwrap
+    script = tmp_path / "fence.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        rank = int(sys.argv[1])
+        reporter = bench._Reporter() if rank == 0 else None
+        line = {{"value": 1.5}}
+        bench.fenced(line, "ok_leg", 30.0, lambda: {{"ms": 2.0}}, rank, reporter)
+        bench.fenced(line, "raised", 30.0, lambda: 1 / 0, rank, reporter)
+        bench.fenced(line, "stuck_leg", 0.5, lambda: time.sleep(120), rank, reporter)
+        raise SystemExit("not reached")
+    """))
+    import bench
+    t0 = __import__("time").time()
+    proc = subprocess.run([sys.executable, str(script), "0"], capture_output=True, timeout=60)
+    assert proc.returncode == bench.EXIT_ABANDONED != 0
+    lines = [l for l in proc.stdout.decode().split("\n") if l]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 1.5 and line["ok_leg"] == {"ms": 2.0} and "ZeroDivisionError" in line["raised"]["error"]
+    assert line["stuck_leg"]["error"].startswith("abandoned after")
+    proc = subprocess.run([sys.executable, str(script), "1"], capture_output=True, timeout=60)
+    assert proc.returncode == bench.EXIT_ABANDONED and not proc.stdout.strip()
+    assert __import__("time").time() - t0 < 40
