@@ -631,6 +631,10 @@ struct Plan {
     hipEvent_t last_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    bool shares_state = false;     // set at build: executions must be ordered (see plan_exec_ordered)
+    hipStream_t s_lines = nullptr; // mfft_lines_host runs on a stream of the plan, so sessions on other plans overlap
+    double* d_lsq_part = nullptr;  // per-block partial sums of the line fit's normal equations (mfft_lines_host)
+    size_t lsq_part_doubles = 0;
 };
 
 // symmetric Hann window of m samples, np.hanning's formula, evaluated in long double
@@ -656,9 +660,11 @@ static void plan_free(Plan* p)
                     (void*)p->d_peaks, (void*)p->d_lines})
         if (q) (void)hipFree(q);
     if (p->s_spec) (void)hipStreamDestroy(p->s_spec);
+    if (p->s_lines) (void)hipStreamDestroy(p->s_lines);
     if (p->ev_spec) (void)hipEventDestroy(p->ev_spec);
     if (p->d_norm) (void)hipFree(p->d_norm);
-    p->s_spec = nullptr; p->ev_spec = nullptr; p->d_norm = nullptr;
+    if (p->d_lsq_part) (void)hipFree(p->d_lsq_part);
+    p->s_spec = nullptr; p->s_lines = nullptr; p->ev_spec = nullptr; p->d_norm = nullptr; p->d_lsq_part = nullptr;
     for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines, (void*)p->h_spec})
         if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {p->ev_in[0], p->ev_in[1], p->ev_run[0], p->ev_run[1], p->ev_out[0], p->ev_out[1], p->last_done})
@@ -733,7 +739,32 @@ template <typename T> static int build_chirpz(Plan* p)
     return MFFT_OK;
 }
 
+static int plan_build_parts(Plan* p);
+
+// Does an execution of this plan touch device state that belongs to the plan rather than to the call?
+// Pass workspaces (several global passes), the chirp-z convolution buffer, the per-call demodulation
+// table, and the dense staging copies around a general single-kernel transform of a segmented layout.
+static bool plan_shares_state(const Plan* p)
+{
+    if (p->kind == Plan::CHIRPZ || (p->flags & MFFT_DEMOD)) return true;
+    if (p->kind != Plan::POW2 && p->kind != Plan::COLUMNS) return false;
+    if (!p->eng.single) return true;
+    if (p->lin.seg == 0 && p->lout.seg == 0) return false;
+    // segmented: only the plain transform over power-of-two segments of at least n / (points per thread)
+    // elements runs without staging (V_SEG in Pow2Engine::exec)
+    const int64_t seg_min = p->n / p->eng.geo.p;
+    const auto fast = [&](int64_t sg) { return sg == 0 || (is_pow2(sg) && sg >= seg_min && sg <= (int64_t(1) << 30)); };
+    return !(p->flags == 0 && p->n_in == p->n && fast(p->lin.seg) && fast(p->lout.seg));
+}
+
 static int plan_build(Plan* p)
+{
+    const int rc = plan_build_parts(p);
+    if (rc == MFFT_OK) p->shares_state = plan_shares_state(p);
+    return rc;
+}
+
+static int plan_build_parts(Plan* p)
 {
     int rc;
     if (p->flags & MFFT_HANN) {
@@ -877,6 +908,25 @@ static int plan_exec(Plan* p, const void* d_in, void* d_out, double scale, doubl
                                 : exec_typed<double>(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
 }
 
+// Every execution goes through here.  A plan that owns per-execution device state is executed by one
+// thread at a time, and an execution on another stream than the previous one first waits, on the
+// device, for that one's completion event -- whichever entry point issued it (mfft_exec on the
+// caller's stream, the host entry points on the null stream or on the plan's own streams).
+static int plan_exec_ordered(Plan* p, const void* d_in, void* d_out, double scale, double mu, double t0, double dt,
+                             double* d_stats, hipStream_t s, int64_t slab = 0, bool tables = true)
+{
+    if (!p->shares_state) return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
+    std::lock_guard<std::mutex> order(p->order_mu);
+    if (!p->last_done) MFFT_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
+    if (p->have_last && p->last_stream != s) MFFT_HIP(hipStreamWaitEvent(s, p->last_done, 0));
+    const int rc = plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
+    // also after a failure part-way: kernels of the passes that were launched may still be running
+    MFFT_HIP(hipEventRecord(p->last_done, s));
+    p->last_stream = s;
+    p->have_last = true;
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // Host side of mfft_exec_host for large batches.  One thread moves pageable memory at 3-5 GB/s
 // (page faults on fresh numpy arrays included) while the bus takes 57 GB/s from pinned memory, so
@@ -936,8 +986,8 @@ static int exec_host_pipelined(Plan* p, const char* h_in, char* h_out, size_t in
         pin.copy(p->pin_in[q], h_in + (size_t)b0 * in_row, (size_t)cnt * in_row);
         PIPE_HIP(hipMemcpyAsync(d_in + (size_t)b0 * in_row, p->pin_in[q], (size_t)cnt * in_row, hipMemcpyHostToDevice, p->s_run));
         PIPE_HIP(hipEventRecord(p->ev_in[q], p->s_run));
-        rc = plan_exec(p, d_in + (size_t)b0 * in_row, d_out + (size_t)b0 * out_row, scale, mu, t0, dt,
-                       p->d_stats ? p->d_stats + 3 * b0 : nullptr, p->s_run, cnt, k == 0);
+        rc = plan_exec_ordered(p, d_in + (size_t)b0 * in_row, d_out + (size_t)b0 * out_row, scale, mu, t0, dt,
+                               p->d_stats ? p->d_stats + 3 * b0 : nullptr, p->s_run, cnt, k == 0);
         if (rc) { (void)hipStreamSynchronize(p->s_run); (void)hipStreamSynchronize(p->s_out); drain(); return rc; }
         if (h_out) {
             PIPE_HIP(hipEventRecord(p->ev_run[q], p->s_run));
@@ -1159,21 +1209,7 @@ int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale, doubl
     if ((p->flags & MFFT_STATS) && !d_stats) { set_error("plan has MFFT_STATS but d_stats is null"); return MFFT_E_INVALID; }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool shared_state = p->kind == Plan::CHIRPZ || (p->flags & MFFT_DEMOD) ||
-                              ((p->kind == Plan::POW2 || p->kind == Plan::COLUMNS) && !p->eng.single);
-    if (!shared_state) return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
-    std::lock_guard<std::mutex> order(p->order_mu);
-    if (!p->last_done) MFFT_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
-    const bool other_stream = p->have_last && p->last_stream != s;
-    if (other_stream) MFFT_HIP(hipStreamWaitEvent(s, p->last_done, 0));
-    const int rc = plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s);
-    if (rc == MFFT_OK) {
-        MFFT_HIP(hipEventRecord(p->last_done, s));
-        p->last_stream = s;
-        p->have_last = true;
-    }
-    return rc;
+    return plan_exec_ordered(p, d_in, d_out, scale, mu, t0, dt, d_stats, static_cast<hipStream_t>(stream));
 }
 
 int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, double mu, double t0,
@@ -1206,7 +1242,7 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
         if (rc != MFFT_OK) return rc;
     } else {
         MFFT_HIP(hipMemcpy(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice));
-        const int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
+        const int rc = plan_exec_ordered(p, p->d_in, p->d_out, scale, mu, t0, dt, p->d_stats, nullptr);
         if (rc != MFFT_OK) return rc;
         if (h_out) MFFT_HIP(hipMemcpy(h_out, p->d_out, out_bytes, hipMemcpyDeviceToHost));
     }
@@ -1353,31 +1389,32 @@ static int static_scratch(double** out)
     return MFFT_OK;
 }
 
-int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n, int64_t batch,
-                           const double* d_mu, const double* d_E, int m, double* d_out, void* stream)
+// The batched normal equations on device arrays: per-sample-block partial sums into `partial`, then
+// the fixed-order final sums into d_out.  Allocates nothing; `partial` holds `partial_doubles` doubles.
+static int lsq_normal_launch(const void* d_x, const double* d_win, const double* d_times, int64_t n, int64_t batch,
+                             const double* d_mu, const double* d_E, int m, double* d_out, double* partial,
+                             size_t partial_doubles, hipStream_t s, const char* who)
 {
-    if (!d_x || !d_times || !d_E || !d_out || n < 1 || batch < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
-    if (m < 1 || m > 64) { set_error("1 <= m <= 64 columns"); return MFFT_E_INVALID; }
-    if (n > (int64_t(1) << 40)) { set_error("n above 2^40 samples"); return MFFT_E_INVALID; }
     const int nchunk = (m + kLsqCols - 1) / kLsqCols;
-    // partial sums: batch * m * nchunk * nblk slots of kLsqSlot doubles, inside the fixed scratch
+    // the grid's z extent first: it also bounds the products below (batch <= 65535, m <= 64)
+    if (batch > 65535 / nchunk) {
+        set_error(std::string(who) + ": at most " + std::to_string(65535 / nchunk) + " signals per call at this column count; split the batch");
+        return MFFT_E_UNSUPPORTED;
+    }
+    // partial sums: batch * m * nchunk * nblk slots of kLsqSlot doubles
     const size_t per_blk = (size_t)batch * (size_t)m * (size_t)nchunk * kLsqSlot;
-    if (per_blk > kScratchDoubles || batch * (int64_t)nchunk > 65535) {
-        set_error("mfft_lsq_normal_static: batch * m * ceil(m/16) * 36 doubles exceed the 2 MiB scratch (" +
-                  std::to_string(per_blk * sizeof(double)) + " bytes needed per sample block); split the batch");
+    if (per_blk > partial_doubles) {
+        set_error(std::string(who) + ": batch * m * ceil(m/16) * 36 doubles exceed the " + std::to_string(partial_doubles * sizeof(double)) +
+                  "-byte scratch (" + std::to_string(per_blk * sizeof(double)) + " bytes needed per sample block); split the batch");
         return MFFT_E_UNSUPPORTED;
     }
     int64_t nblk = (n + 255) / 256;
     if (nblk > 64) nblk = 64;
-    if ((size_t)nblk > kScratchDoubles / per_blk) nblk = (int64_t)(kScratchDoubles / per_blk);
-    double* d_scratch = nullptr;
-    const int rc = static_scratch(&d_scratch);
-    if (rc) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((size_t)nblk > partial_doubles / per_blk) nblk = (int64_t)(partial_doubles / per_blk);
     LsqBatchArgs a;
     a.x = static_cast<const cx<double>*>(d_x);
     a.win = d_win; a.times = d_times; a.mu = d_mu; a.E = d_E;
-    a.partial = d_scratch;
+    a.partial = partial;
     a.n = n; a.m = m; a.nchunk = nchunk; a.nblk = (int)nblk;
     // every partial slot that lsq_final_kernel reads is written by exactly one block of this launch,
     // so nothing in the scratch has to start at zero and no stale value of an earlier call is read
@@ -1386,10 +1423,23 @@ int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d
     const int64_t total = (int64_t)per_blk;               // one wave per value
     int64_t fblocks = (total + 3) / 4;
     if (fblocks > 2048) fblocks = 2048;
-    hipLaunchKernelGGL(lsq_final_kernel, dim3((unsigned)fblocks), dim3(256), 0, s, (const double*)d_scratch, d_out,
+    hipLaunchKernelGGL(lsq_final_kernel, dim3((unsigned)fblocks), dim3(256), 0, s, (const double*)partial, d_out,
                        (int)batch, m, nchunk, (int)nblk);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
+}
+
+int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n, int64_t batch,
+                           const double* d_mu, const double* d_E, int m, double* d_out, void* stream)
+{
+    if (!d_x || !d_times || !d_E || !d_out || n < 1 || batch < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (m < 1 || m > 64) { set_error("1 <= m <= 64 columns"); return MFFT_E_INVALID; }
+    if (n > (int64_t(1) << 40)) { set_error("n above 2^40 samples"); return MFFT_E_INVALID; }
+    double* d_scratch = nullptr;
+    const int rc = static_scratch(&d_scratch);
+    if (rc) return rc;
+    return lsq_normal_launch(d_x, d_win, d_times, n, batch, d_mu, d_E, m, d_out, d_scratch, kScratchDoubles,
+                             static_cast<hipStream_t>(stream), "mfft_lsq_normal_static");
 }
 
 int mfft_local_maxima(const void* d_S, int64_t n, int dtype, int64_t* d_idx, int64_t capacity,
@@ -1449,7 +1499,7 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
     double* d_stats = reinterpret_cast<double*>(p->d_peaks);
     MFFT_HIP(hipMemcpyAsync(p->d_in, h_in, in_bytes, hipMemcpyHostToDevice, nullptr));
     MFFT_HIP(hipMemsetAsync(p->d_peaks, 0, sizeof(int64_t) * kHead, nullptr));
-    int rc = plan_exec(p, p->d_in, p->d_out, scale, mu, t0, dt, d_stats, nullptr);
+    int rc = plan_exec_ordered(p, p->d_in, p->d_out, scale, mu, t0, dt, d_stats, nullptr);
     if (rc) return rc;
     rc = mfft_local_maxima(p->d_out, p->n, p->dtype, p->d_peaks + kHead, capacity, p->d_peaks + 3, nullptr);
     if (rc) return rc;
@@ -1519,12 +1569,18 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     if (!p->d_lines || p->lines_want != want) {
         if (p->d_lines) (void)hipFree(p->d_lines);
         if (p->h_lines) (void)hipHostFree(p->h_lines);
+        if (p->d_lsq_part) (void)hipFree(p->d_lsq_part);       // sized by the line count
+        p->d_lsq_part = nullptr; p->lsq_part_doubles = 0;
         p->d_lines = nullptr; p->h_lines = nullptr; p->lines_want = 0;
         MFFT_HIP(hipMalloc((void**)&p->d_lines, total));
         MFFT_HIP(hipHostMalloc((void**)&p->h_lines, up_bytes + down_bytes, hipHostMallocDefault));
         p->lines_want = want;
         p->lines_dirty = true;
     }
+    // the whole call runs on a stream of the plan: calls on other plans (other sessions) overlap on the
+    // device instead of queueing on the null stream
+    if (!p->s_lines) MFFT_HIP(hipStreamCreateWithFlags(&p->s_lines, hipStreamNonBlocking));
+    hipStream_t sm = p->s_lines;
     char* d = p->d_lines;
     char* h_up = p->h_lines;
     char* h_down = p->h_lines + up_bytes;
@@ -1542,8 +1598,14 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
 
     memcpy(h_up + o_x, h_x, in_bytes);
     if (h_gram) memcpy(h_up + o_t, h_times, sizeof(double) * (size_t)n_in);
-    MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, nullptr));
-    int rc = plan_exec(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, nullptr);
+    // no return may leave this stream (or the side stream below) working on the plan's buffers, or writing
+    // into its pinned ones, behind the caller's back
+    struct StreamSync {
+        hipStream_t s; bool armed;
+        ~StreamSync() { if (armed) (void)hipStreamSynchronize(s); }
+    } main_sync{sm, true};
+    MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, sm));
+    int rc = plan_exec_ordered(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, sm);
     if (rc) return rc;
     // The spectra leave on a stream of their own as soon as the transform is done -- normalised into a
     // copy, because the line search reads the unnormalised ones meanwhile -- and land in pinned memory
@@ -1569,13 +1631,9 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
         MFFT_HIP(hipGetLastError());
         return MFFT_OK;
     };
-    // (no return may leave the side stream writing into the plan's pinned buffer behind the caller's back)
-    struct SideSync {
-        hipStream_t s; bool armed;
-        ~SideSync() { if (armed) (void)hipStreamSynchronize(s); }
-    } side_sync{p->s_spec, side};
+    StreamSync side_sync{p->s_spec, side};
     if (side) {
-        MFFT_HIP(hipEventRecord(p->ev_spec, nullptr));
+        MFFT_HIP(hipEventRecord(p->ev_spec, sm));
         MFFT_HIP(hipStreamWaitEvent(p->s_spec, p->ev_spec, 0));
         if (normalize) { rc = normalise(p->d_norm, p->s_spec); if (rc) return rc; }
         MFFT_HIP(hipMemcpyAsync(p->h_spec, normalize ? p->d_norm : p->d_out, out_bytes, hipMemcpyDeviceToHost, p->s_spec));
@@ -1587,56 +1645,64 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     a.include_dc = prm->include_dc; a.mode = prm->mode; a.want = want;
     // the pick kernel leaves the candidate counters at zero; they are cleared here only after a
     // (re)allocation or when an earlier call stopped between the two kernels
-    if (p->lines_dirty) MFFT_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)B, nullptr));
+    if (p->lines_dirty) MFFT_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)B, sm));
     p->lines_dirty = true;
     int64_t blocks = (n + kPeakChunk - 1) / kPeakChunk;
     if (blocks > 1024) blocks = 1024;
     const int pick_threads = n >= 16384 ? 1024 : 256;
     if (p->dtype == MFFT_C64) {
-        hipLaunchKernelGGL(peak_candidates_kernel<float>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
+        hipLaunchKernelGGL(peak_candidates_kernel<float>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, sm,
                            static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt);
-        hipLaunchKernelGGL(peak_pick_kernel<float>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
+        hipLaunchKernelGGL(peak_pick_kernel<float>, dim3((unsigned)B), dim3(pick_threads), 0, sm,
                            static_cast<const float*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n, h_gram ? d_E : nullptr);
     } else {
-        hipLaunchKernelGGL(peak_candidates_kernel<double>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, nullptr,
+        hipLaunchKernelGGL(peak_candidates_kernel<double>, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, sm,
                            static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt);
-        hipLaunchKernelGGL(peak_pick_kernel<double>, dim3((unsigned)B), dim3(pick_threads), 0, nullptr,
+        hipLaunchKernelGGL(peak_pick_kernel<double>, dim3((unsigned)B), dim3(pick_threads), 0, sm,
                            static_cast<const double*>(p->d_out), a, d_cidx, d_cval, d_cnt, d_idx, d_om, d_h, d_n, h_gram ? d_E : nullptr);
     }
     MFFT_HIP(hipGetLastError());
     p->lines_dirty = false;
     if (h_gram) {
-        // sub-batches sized to the fixed scratch of the reduction
+        // The reduction's partial sums live in a block of the plan (not in the scratch of
+        // mfft_lsq_normal_static, which belongs to that entry point's callers): sized for the whole batch
+        // up to 16 MiB, larger batches go through it in sub-batches.
         const int nchunk = (want + kLsqCols - 1) / kLsqCols;
-        int64_t per = (int64_t)(kScratchDoubles / ((size_t)want * nchunk * kLsqSlot));
+        const size_t per_sig = (size_t)want * nchunk * kLsqSlot;          // doubles per signal and sample block
+        if (!p->d_lsq_part) {
+            size_t doubles = per_sig * (size_t)B * 64;
+            const size_t cap = (size_t(16) << 20) / sizeof(double);
+            if (doubles > cap) doubles = cap < per_sig ? per_sig : cap;
+            MFFT_HIP(hipMalloc((void**)&p->d_lsq_part, doubles * sizeof(double)));
+            p->lsq_part_doubles = doubles;
+        }
+        int64_t per = (int64_t)(p->lsq_part_doubles / per_sig);
         if (per > 65535 / nchunk) per = 65535 / nchunk;
         if (per < 1) { set_error("line fit does not fit the reduction scratch"); return MFFT_E_UNSUPPORTED; }
-        // the reduction's scratch is one array per GPU: keep other threads' launches out of the
-        // partial -> final pairs (all of them go to the null stream, so launch order is execution order)
-        static std::mutex scratch_mu;
-        std::lock_guard<std::mutex> scratch_lock(scratch_mu);
         for (int64_t b0 = 0; b0 < B; b0 += per) {
             const int64_t nb = B - b0 < per ? B - b0 : per;
-            rc = mfft_lsq_normal_static(reinterpret_cast<const cx<double>*>(d + o_x) + b0 * n_in,
-                                        (p->flags & MFFT_HANN) ? static_cast<const double*>(p->d_win) : nullptr, d_t, n_in,
-                                        nb, nullptr, d_E + b0 * want, want, d_gram + (size_t)b0 * nres, nullptr);
+            rc = lsq_normal_launch(reinterpret_cast<const cx<double>*>(d + o_x) + b0 * n_in,
+                                   (p->flags & MFFT_HANN) ? static_cast<const double*>(p->d_win) : nullptr, d_t, n_in,
+                                   nb, nullptr, d_E + b0 * want, want, d_gram + (size_t)b0 * nres, p->d_lsq_part,
+                                   p->lsq_part_doubles, sm, "mfft_lines_host");
             if (rc) return rc;
         }
     }
-    MFFT_HIP(hipMemcpyAsync(h_down, d + o_down, h_gram ? down_bytes : (o_gram - o_down), hipMemcpyDeviceToHost, nullptr));
+    MFFT_HIP(hipMemcpyAsync(h_down, d + o_down, h_gram ? down_bytes : (o_gram - o_down), hipMemcpyDeviceToHost, sm));
     if (h_S && !side) {                                   // small spectra, or too large for a pinned copy
-        if (normalize) { rc = normalise(p->d_out, nullptr); if (rc) return rc; }
-        MFFT_HIP(hipMemcpyAsync(h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        if (normalize) { rc = normalise(p->d_out, sm); if (rc) return rc; }
+        MFFT_HIP(hipMemcpyAsync(h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, sm));
     }
     uint64_t ticket = 0;
     const bool pooled = side;
     if (side) {
         const hipError_t e_side = hipStreamSynchronize(p->s_spec);
         side_sync.armed = false;
-        if (e_side != hipSuccess) { (void)hipStreamSynchronize(nullptr); return hip_fail(e_side, "spectrum download", __FILE__, __LINE__); }
+        if (e_side != hipSuccess) return hip_fail(e_side, "spectrum download", __FILE__, __LINE__);
         ticket = CopyPool::out().start(h_S, p->h_spec, out_bytes);
     }
-    const hipError_t e_main = hipStreamSynchronize(nullptr);
+    const hipError_t e_main = hipStreamSynchronize(sm);
+    main_sync.armed = false;
     if (e_main != hipSuccess) { if (pooled) CopyPool::out().wait(ticket); return hip_fail(e_main, "line search", __FILE__, __LINE__); }
     memcpy(h_stats, h_down + (o_stats - o_down), sizeof(double) * 3 * (size_t)B);
     memcpy(h_idx, h_down + (o_idx - o_down), sizeof(int64_t) * (size_t)(B * want));

@@ -15,10 +15,14 @@
  * never throw.  mfft_last_error() returns a thread-local detail string.  Plans
  * are bound to the HIP device that was current when they were created.  A plan
  * may be executed from several host threads and on several streams: executions
- * of the SAME plan that share its workspace (multi-pass, chirp-z and
- * demodulating plans) are ordered by the library, on the host and -- through a
- * completion event -- on the device; distinct plans are independent.  "d_"
- * pointers are device memory, "h_" pointers host memory.
+ * of the SAME plan that share device state of the plan (pass workspaces, the
+ * chirp-z convolution buffer, the demodulation table, the staging copies of a
+ * windowed / padded transform over a segmented layout) are ordered by the
+ * library, on the host and -- through a completion event -- on the device,
+ * whichever entry point issues them (mfft_exec on the caller's stream, the host
+ * entry points on streams of their own); distinct plans are independent and
+ * overlap on the device.  "d_" pointers are device memory, "h_" pointers host
+ * memory.
  */
 #ifndef MFFT_H
 #define MFFT_H
@@ -174,7 +178,8 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
  * unnormalised spectra), h_idx / h_omega_hat / h_height
  * batch*want in pick order (idx -1 beyond h_count[b]; h_height may be NULL), h_gram batch *
  * (2*want*want + 2*want + 1) doubles (columns beyond h_count[b] carry E = 0 and are to be ignored).
- * Synchronous; one upload and one download per array. */
+ * Synchronous; one upload and one download per array.  The device work runs on a stream of the plan, so
+ * calls on different plans from different host threads (one Streamlit session each) overlap. */
 typedef struct mfft_peak_params {
     double dt;          /* sample spacing of the time series (sets the omega axis) */
     double dc_guard;    /* mode 0, include_dc == 0: candidates need |omega| > dc_guard */
@@ -214,11 +219,11 @@ int mfft_lsq_normal_host(const void* h_x, const double* h_win, const double* h_t
  * The per-block partial sums live in a fixed 2 MiB device array inside the library (one per GPU,
  * held until the process ends), so a call is refused with MFFT_E_UNSUPPORTED when
  * batch * m * ceil(m/16) * 36 doubles exceed it (m = 6: 1213 signals; m = 64: 28); split larger
- * batches.  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
- * two threads) race -- serialise them; mfft_lines_host's fit uses the same array (on the null
- * stream, its launches kept together by a lock inside the library), so a call made on another
- * stream while a line search runs on that GPU races with it too.  The first call on each device resolves the array's
- * address and should be made outside graph capture.  Results are deterministic (fixed summation
+ * batches (at most 65535 / ceil(m/16) signals per call in any case).  All calls of THIS entry point on
+ * one GPU share that array: two of them that overlap on one GPU (two streams, two threads) race --
+ * serialise them.  Nothing else in the library touches the array (mfft_lines_host's fit keeps its
+ * partial sums in a block of its plan), so a call may overlap any other entry point.  The first call on
+ * each device resolves the array's address and should be made outside graph capture.  Results are deterministic (fixed summation
  * order, no atomics) and agree with mfft_lsq_normal_host to rounding (1e-13 relative). */
 int mfft_lsq_normal_static(const void* d_x, const double* d_win, const double* d_times, int64_t n,
                            int64_t batch, const double* d_mu, const double* d_E, int m, double* d_out,

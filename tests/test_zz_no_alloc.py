@@ -49,6 +49,14 @@ def _case(lib, check, torch, n, batch, m, use_win, use_mu, seed, poison):
         assert np.linalg.norm(Gs - G) <= 1e-12 * np.linalg.norm(G), (n, batch, m, b)
         assert np.linalg.norm(rs - r) <= 1e-12 * max(np.linalg.norm(r), np.sqrt(yy * G[0, 0].real)), (n, batch, m, b)
         assert abs(out[b, -1] - yy) <= 1e-12 * yy
+        # and directly against numpy: B^H B, B^H y, y^H y of the reference's basis (final2.py:174-175)
+        w = win if win is not None else np.ones(n)
+        basis = np.exp(-1j * np.outer(times, E[b])) * w[:, None]
+        y = x[b] * w * np.exp(1j * mu[b] * times)
+        nb, ny = np.linalg.norm(basis), np.linalg.norm(y)
+        assert np.linalg.norm(Gs - basis.conj().T @ basis) <= 1e-12 * nb * nb, (n, batch, m, b)
+        assert np.linalg.norm(rs - basis.conj().T @ y) <= 1e-12 * nb * ny, (n, batch, m, b)
+        assert abs(out[b, -1] - ny * ny) <= 1e-12 * ny * ny
     return out
 
 
@@ -77,6 +85,16 @@ def test_static_scratch_limits_are_refused():
     # m = 64 needs 64*4*36 doubles per signal and sample block: 29 signals exceed the 2 MiB scratch
     assert lib.mfft_lsq_normal_static(p, None, p, 8, 29, None, p, 64, p, None) == _lib.E_UNSUPPORTED
     assert b"scratch" in lib.mfft_last_error()
+    # ... and 28 signals fit (buffers of the real extents: the call computes)
+    big_x = torch.zeros(28 * 8 * 2, dtype=torch.float64, device="cuda")
+    big_E = torch.zeros(28 * 64, dtype=torch.float64, device="cuda")
+    big_out = torch.zeros(28 * (2 * 64 * 64 + 2 * 64 + 1), dtype=torch.float64, device="cuda")
+    assert lib.mfft_lsq_normal_static(big_x.data_ptr(), None, p, 8, 28, None, big_E.data_ptr(), 64, big_out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    # batch counts whose products would wrap 64-bit arithmetic are refused by the batch bound, not divided by
+    for huge in (1 << 62, (1 << 63) - 1, 1 << 40, 65536):
+        assert lib.mfft_lsq_normal_static(p, None, p, 8, huge, None, p, 64, p, None) == _lib.E_UNSUPPORTED
+        assert b"split the batch" in lib.mfft_last_error()
     assert lib.mfft_lsq_normal_static(p, None, p, 8, 1, None, p, 65, p, None) == _lib.E_INVALID
     assert lib.mfft_lsq_normal_static(p, None, p, 0, 1, None, p, 4, p, None) == _lib.E_INVALID
     assert lib.mfft_lsq_normal_static(None, None, p, 8, 1, None, p, 4, p, None) == _lib.E_INVALID
