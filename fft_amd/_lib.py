@@ -46,6 +46,7 @@ SIGNATURES = {
     "mfft_plan_1d_layout": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _u32,
                                    ctypes.POINTER(Layout), ctypes.POINTER(Layout)]),
     "mfft_plan_1d_columns": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _i64, _i64]),
+    "mfft_plan_1d_columns_ld": (_int, [ctypes.POINTER(_vp), _i64, _i64, _i64, _int, _i64, _i64, _i64]),
     "mfft_plan_destroy": (_int, [_vp]),
     "mfft_plan_workspace_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
     "mfft_plan_launches": (_int, [_vp, ctypes.POINTER(_int)]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "mfft_normalize_by_max": (_int, [_vp, _vp, _i64, _vp, _int, _vp]),
     "mfft_transpose": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "mfft_swap_axes": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "mfft_swap_axes_strided": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "mfft_twiddle_tile": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "mfft_comm_unique_id": (_int, [_vp]),
     "mfft_comm_init_rank": (_int, [ctypes.POINTER(_vp), _int, _int, _vp]),
@@ -69,10 +71,10 @@ SIGNATURES = {
     "mfft_comm_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "mfft_comm_destroy": (_int, [_vp]),
     "mfft_comm_exchange": (_int, [_vp, _vp, _vp, _i64, _vp]),
-    "mfft_plan_2d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int]),
-    "mfft_plan_1d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int]),
+    "mfft_plan_2d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int, _int]),
+    "mfft_plan_1d_dist": (_int, [ctypes.POINTER(_vp), _vp, _i64, _i64, _int, _int, _int, _int]),
     "mfft_dist_exec": (_int, [_vp, _vp, _vp, _vp]),
-    "mfft_dist_plan_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_i64)]),
+    "mfft_dist_plan_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_i64)]),
     "mfft_dist_plan_destroy": (_int, [_vp]),
 }
 

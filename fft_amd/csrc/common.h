@@ -17,6 +17,11 @@ __host__ __device__ inline int64_t seg_index(int64_t j, int64_t seg, int64_t seg
 {
     return seg > 0 ? (j / seg) * seg_stride + (j % seg) : j;
 }
+// the same for a power-of-two segment given as a shift (lseg = 30 describes a dense signal)
+__host__ __device__ inline int64_t seg_pos(int64_t j, int lseg, int64_t seg_stride)
+{
+    return (j >> lseg) * seg_stride + (j & ((int64_t(1) << lseg) - 1));
+}
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define MFFT_HIP(call)                                                        \
@@ -66,6 +71,16 @@ template <typename T> struct KArgs {
     // (j & ((1 << lseg) - 1)); lseg = 30 describes a dense signal.
     int in_lseg, out_lseg;
 };
+
+// Segments the plain segmented variant (V_SEG) serves without staging: powers of two up to 2^30 that hold
+// whole rows of a signal's n / p elements (p points per thread), or -- shorter -- at least one wave's 64
+// elements and one 1 KiB piece of the LDS-DMA loads.
+inline bool seg_is_fast(int64_t seg, int64_t n, int points_per_thread, int dtype)
+{
+    if (seg == 0) return true;
+    if (!is_pow2(seg) || seg > (int64_t(1) << 30)) return false;
+    return seg >= n / points_per_thread || seg >= (dtype == MFFT_C64 ? 128 : 64);
+}
 
 // kernel variants
 enum Variant {

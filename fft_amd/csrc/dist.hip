@@ -4,10 +4,13 @@
 // Built on the library's own public entry points (mfft_plan_1d_layout, mfft_plan_1d_columns,
 // mfft_exec, mfft_swap_axes, mfft_transpose) for everything local, and on RCCL for the exchange
 // steps: every exchange is a group of point-to-point ncclSend / ncclRecv pairs -- what an
-// all-to-all is made of -- cut into row chunks, so that a chunk is on the xGMI links (a full mesh:
-// every peer pair has its own link, one hop per message) while the next one is being produced or
-// the previous one consumed.  Exchanges run on a stream of their own; events order them against
-// the caller's stream, on which all kernels run.
+// all-to-all is made of -- on the xGMI links (a full mesh: every peer pair has its own link, one hop
+// per message).  The data is cut two ways so that the links never wait for a local step and no local
+// step waits for the whole exchange: into GROUPS OF COLUMNS, each of which is exchanged, transformed
+// along the strided axis and sent on as a unit while the next group is still arriving, and -- for the
+// group at either end of the pipeline -- into row chunks, so that the step before the first exchange
+// and the step after the last one overlap them too.  Exchanges run on a stream of their own, in one
+// fixed order on every rank; events order them against the caller's stream, on which all kernels run.
 //
 // RCCL is loaded on first use (dlopen by soname, so a process that already holds a copy -- PyTorch
 // ships one -- shares it); single-GPU users of libmfft.so never load it.  A second communicator
@@ -118,11 +121,18 @@ struct Comm {
             const int rc = rccl(&r);
             if (rc) return rc;
             MFFT_NCCL(r, r->GroupStart());
-            for (int p = 0; p < world; ++p) {
-                MFFT_NCCL(r, r->Send(send[p], bytes, ncclChar, p, nccl, s));
-                MFFT_NCCL(r, r->Recv(recv[p], bytes, ncclChar, p, nccl, s));
+            ncclResult_t bad = ncclSuccess;
+            const char* what = "";
+            for (int p = 0; p < world && bad == ncclSuccess; ++p) {
+                bad = r->Send(send[p], bytes, ncclChar, p, nccl, s);
+                what = "ncclSend";
+                if (bad == ncclSuccess) { bad = r->Recv(recv[p], bytes, ncclChar, p, nccl, s); what = "ncclRecv"; }
             }
-            MFFT_NCCL(r, r->GroupEnd());
+            // the group is closed also after a failure: left open on this thread, later RCCL calls would
+            // be queued into it and the peers would wait for them
+            const ncclResult_t ended = r->GroupEnd();
+            if (bad != ncclSuccess) { set_error(std::string(what) + " failed: " + r->GetErrorString(bad)); return MFFT_E_HIP; }
+            if (ended != ncclSuccess) { set_error(std::string("ncclGroupEnd failed: ") + r->GetErrorString(ended)); return MFFT_E_HIP; }
             return MFFT_OK;
         }
         LocalGroup& g = *group;
@@ -153,6 +163,19 @@ static int chunk_count(int requested, int64_t rows, int world)
     return (int)(c < 1 ? 1 : c);
 }
 
+// Column groups: the largest divisor of this rank's `cols` columns not above the request (default 4) that
+// leaves groups of at least 64 (complex128) / 128 (complex64) columns -- the shortest segments the
+// contiguous-axis kernels read and write in place, and at least a 1 KiB run per row of a group.
+static int group_count(int requested, int64_t cols, int world, int dtype)
+{
+    if (world == 1) return 1;
+    int64_t g = requested > 0 ? requested : 4;
+    const int64_t floor_w = dtype == MFFT_C64 ? 128 : 64;
+    if (g > cols) g = cols;
+    while (g > 1 && (cols % g || cols / g < floor_w)) --g;
+    return (int)(g < 1 ? 1 : g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------
@@ -162,13 +185,16 @@ struct DistPlan {
     int dtype = 0, device = 0;
     int64_t a0 = 0, a1 = 0;            // 2-D: n0, n1;  1-D: n1, n2
     int option = 0;                    // 2-D: restore_layout;  1-D: natural_order
-    int chunks = 1;
+    int chunks = 1;                    // row chunks of the first group's first exchange and the last group's last
+    int groups = 1;                    // column groups
     mfft_plan rows = nullptr;          // contiguous-axis transforms of one row chunk
-    mfft_plan cols = nullptr;          // strided-axis transforms (column-batched)
+    std::vector<mfft_plan> cols;       // strided-axis transforms (column-batched) of one column group: one plan, or -- 1-D,
+                                       // whose fused twiddle depends on the group's first column -- one per group
     void* buf[2] = {nullptr, nullptr}; // two buffers of the local size
     size_t local_bytes = 0;
     hipStream_t s_comm = nullptr;
-    std::vector<hipEvent_t> ev;        // producer -> exchange, exchange -> consumer, per chunk
+    std::vector<hipEvent_t> ev;        // stream-to-stream hand-offs of one execution, taken in turn
+    size_t ev_next = 0;
     std::mutex mu;
 
     ~DistPlan()
@@ -177,22 +203,39 @@ struct DistPlan {
         const bool have = hipGetDevice(&prev) == hipSuccess;
         (void)hipSetDevice(device);
         if (rows) (void)mfft_plan_destroy(rows);
-        if (cols) (void)mfft_plan_destroy(cols);
+        for (mfft_plan c : cols) if (c) (void)mfft_plan_destroy(c);
         for (void* b : buf) if (b) (void)hipFree(b);
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
         if (s_comm) (void)hipStreamDestroy(s_comm);
         if (have) (void)hipSetDevice(prev);
     }
-    hipEvent_t& produced(int c) { return ev[(size_t)(2 * c)]; }
-    hipEvent_t& arrived(int c) { return ev[(size_t)(2 * c + 1)]; }
+    mfft_plan col_plan(int g) const { return cols.size() == 1 ? cols[0] : cols[(size_t)g]; }
+    // `to` continues only after everything enqueued on `from` so far.  An event may be recorded again once
+    // the wait on its previous record has been enqueued, so a fixed pool taken in turn is enough.
+    int link(hipStream_t from, hipStream_t to)
+    {
+        hipEvent_t e = ev[ev_next++ % ev.size()];
+        MFFT_HIP(hipEventRecord(e, from));
+        MFFT_HIP(hipStreamWaitEvent(to, e, 0));
+        return MFFT_OK;
+    }
+    // an event of its own (recorded now on `from`, waited for later)
+    int mark(hipStream_t from, hipEvent_t* out)
+    {
+        *out = ev[ev_next++ % ev.size()];
+        MFFT_HIP(hipEventRecord(*out, from));
+        return MFFT_OK;
+    }
 };
 
-static int plan_common(DistPlan* p, size_t local_elems, int nchunks)
+static int plan_common(DistPlan* p, size_t local_elems)
 {
     p->local_bytes = local_elems * elem_size(p->dtype);
     for (void*& b : p->buf) MFFT_HIP(hipMalloc(&b, p->local_bytes));
     MFFT_HIP(hipStreamCreateWithFlags(&p->s_comm, hipStreamNonBlocking));
-    p->ev.assign((size_t)(2 * nchunks + 2), nullptr);
+    // one execution takes at most 3 * (groups + chunks) + 8 events; marks stay valid while fewer than the
+    // pool's size are taken after them
+    p->ev.assign((size_t)(8 * (p->groups + p->chunks) + 16), nullptr);
     for (hipEvent_t& e : p->ev) MFFT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return MFFT_OK;
 }
@@ -209,156 +252,203 @@ static void block_ptrs(std::vector<const void*>* send, std::vector<void*>* recv,
     }
 }
 
-// 2-D: out-of-place on this rank's R = n0/P rows (row-major, n1 columns)
+#define MFFT_TRY(call) do { const int rc__ = (call); if (rc__) return rc__; } while (0)
+
+// 2-D: out-of-place on this rank's R = n0/P rows (row-major, n1 columns).
+//
+// The n1 columns are cut into P*G segments of Wc = n1/(P*G) columns; rank q transforms, as its group g,
+// segment s(q, g) = q*G + g when the result stays in column slabs (its columns must be the contiguous
+// range [q*W, (q+1)*W)) and g*P + q when the row-slab layout is restored (any assignment serves, and this
+// one lets every group's buffers be reused as soon as that group has moved on).
+//   rows      bin k of local row i is stored at [k / Wc][i][k % Wc]: every (peer, group) block contiguous
+//   exchange  group-major; the first group in row chunks, each leaving as soon as its rows are transformed
+//   columns   group g is transformed along the strided axis as soon as it has arrived, while group g + 1
+//             travels -- straight into its column block of the result, or (restore_layout) into the send
+//             buffer of the way back, which leaves while group g + 1 is transformed
+//   unpack    (restore_layout) the last group travels in row chunks; a chunk's rows are unpacked while the
+//             next chunk is on the links
 static int exec_2d(DistPlan* p, const char* in, char* out, hipStream_t s)
 {
     Comm& cm = *p->comm;
-    const int P = cm.world, C = p->chunks;
-    const int64_t n0 = p->a0, n1 = p->a1, R = n0 / P, W = n1 / P, Rc = R / C;
+    const int P = cm.world, C = p->chunks, G = p->groups;
+    const int64_t n0 = p->a0, n1 = p->a1, R = n0 / P, W = n1 / P, Rc = R / C, Wc = W / G;
     const size_t es = elem_size(p->dtype);
     char* X = static_cast<char*>(p->buf[0]);
     char* Y = static_cast<char*>(p->buf[1]);
+    hipStream_t sc = p->s_comm;
     std::vector<const void*> snd;
     std::vector<void*> rcv;
-    int rc;
-    // row transforms; bin k of local row i is stored at [k / W][i][k % W] of the chunk's send
-    // buffer: already packed per destination.  Chunk c travels while chunk c + 1 is transformed and
-    // lands as rows [r*R + c*Rc, +Rc) of the (n0 x W) column matrix.
-    MFFT_HIP(hipEventRecord(p->arrived(C), s));                 // the buffers are free once earlier work on s is done
-    MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->arrived(C), 0));
+    p->ev_next = 0;
     if (P == 1) {                                              // nothing to exchange: rows land in the column matrix
-        rc = mfft_exec(p->rows, in, Y, 1.0, 0.0, 0.0, 1.0, nullptr, s);
-        if (rc) return rc;
-        return mfft_exec(p->cols, Y, out, 1.0, 0.0, 0.0, 1.0, nullptr, s);
+        MFFT_TRY(mfft_exec(p->rows, in, Y, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        return mfft_exec(p->col_plan(0), Y, out, 1.0, 0.0, 0.0, 1.0, nullptr, s);
     }
+    const bool restore = p->option != 0;
+    const size_t blk = (size_t)R * Wc * es;                    // one (peer, group) block: R rows of Wc columns
+    const size_t gsz = (size_t)P * blk;                        // one group's (n0 x Wc) column matrix
+    const auto seg_of = [&](int q, int g) { return restore ? (size_t)g * P + q : (size_t)q * G + g; };
+    MFFT_TRY(p->link(s, sc));                                  // the buffers are free once earlier work on s is done
+    std::vector<hipEvent_t> rows_done((size_t)C), here((size_t)G), back((size_t)C);
     for (int c = 0; c < C; ++c) {
-        const size_t chunk = (size_t)c * (size_t)Rc * (size_t)n1 * es;
-        rc = mfft_exec(p->rows, in + chunk, X + chunk, 1.0, 0.0, 0.0, 1.0, nullptr, s);
-        if (rc) return rc;
-        MFFT_HIP(hipEventRecord(p->produced(c), s));
-        MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->produced(c), 0));
-        block_ptrs(&snd, &rcv, P, X + chunk, (size_t)Rc * W * es, 0, Y, (size_t)R * W * es, (size_t)c * Rc * W * es);
-        rc = cm.exchange(snd.data(), rcv.data(), (size_t)Rc * W * es, p->s_comm);
-        if (rc) return rc;
+        MFFT_TRY(mfft_exec(p->rows, in + (size_t)c * Rc * n1 * es, X + (size_t)c * Rc * Wc * es, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        MFFT_TRY(p->mark(s, &rows_done[(size_t)c]));
     }
-    MFFT_HIP(hipEventRecord(p->arrived(0), p->s_comm));
-    MFFT_HIP(hipStreamWaitEvent(s, p->arrived(0), 0));
-    // column transforms on the strided columns where the exchange left them (no transpose)
-    if (!p->option)
-        return mfft_exec(p->cols, Y, out, 1.0, 0.0, 0.0, 1.0, nullptr, s);
-    rc = mfft_exec(p->cols, Y, X, 1.0, 0.0, 0.0, 1.0, nullptr, s);      // X[k0][c] = F[k0][rank*W + c]
-    if (rc) return rc;
-    // way back: rows [q*R, (q+1)*R) belong to rank q and are contiguous; they travel in row chunks,
-    // and a chunk that has arrived ([q][i][c], P x Rc x W) is unpacked into its Rc output rows while
-    // the next one is on the links
-    MFFT_HIP(hipEventRecord(p->produced(0), s));
-    MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->produced(0), 0));
+    for (int g = 0; g < G; ++g) {
+        const int nck = g == 0 ? C : 1;
+        const size_t piece = blk / nck;
+        for (int c = 0; c < nck; ++c) {
+            if (g == 0) MFFT_HIP(hipStreamWaitEvent(sc, rows_done[(size_t)c], 0));
+            snd.resize((size_t)P); rcv.resize((size_t)P);
+            for (int q = 0; q < P; ++q) {
+                snd[(size_t)q] = X + seg_of(q, g) * blk + (size_t)c * piece;
+                rcv[(size_t)q] = Y + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;       // rows [q*R + c*R/nck, ...) of group g
+            }
+            MFFT_TRY(cm.exchange(snd.data(), rcv.data(), piece, sc));
+        }
+        MFFT_TRY(p->mark(sc, &here[(size_t)g]));
+    }
+    for (int g = 0; g < G; ++g) {
+        MFFT_HIP(hipStreamWaitEvent(s, here[(size_t)g], 0));
+        if (!restore) {                                        // out[k0][rank's column g*Wc + w]: rows W elements apart
+            MFFT_TRY(mfft_exec(p->col_plan(g), Y + (size_t)g * gsz, out + (size_t)g * Wc * es, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+            continue;
+        }
+        // group g's send blocks have left (its exchange is complete): their region takes the transformed group,
+        // whose rows [q*R, (q+1)*R) belong to rank q and are contiguous
+        MFFT_TRY(mfft_exec(p->col_plan(g), Y + (size_t)g * gsz, X + (size_t)g * gsz, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        MFFT_TRY(p->link(s, sc));
+        const int nck = g == G - 1 ? C : 1;
+        const size_t piece = blk / nck;
+        for (int c = 0; c < nck; ++c) {
+            snd.resize((size_t)P); rcv.resize((size_t)P);
+            for (int q = 0; q < P; ++q) {
+                snd[(size_t)q] = X + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;
+                rcv[(size_t)q] = Y + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;       // [segment g*P + q][row][w]
+            }
+            MFFT_TRY(cm.exchange(snd.data(), rcv.data(), piece, sc));
+            if (g == G - 1) MFFT_TRY(p->mark(sc, &back[(size_t)c]));
+        }
+    }
+    if (!restore) return MFFT_OK;
+    // Y[s][i][w] = F[rank*R + i][s*Wc + w]: out[i][s][w], Rc rows at a time as the last group's chunks arrive
     for (int c = 0; c < C; ++c) {
-        const size_t piece = (size_t)Rc * W * es;
-        block_ptrs(&snd, &rcv, P, X, (size_t)R * W * es, (size_t)c * piece, Y + (size_t)c * P * piece, piece, 0);
-        rc = cm.exchange(snd.data(), rcv.data(), piece, p->s_comm);
-        if (rc) return rc;
-        MFFT_HIP(hipEventRecord(p->arrived(c), p->s_comm));
-        MFFT_HIP(hipStreamWaitEvent(s, p->arrived(c), 0));
-        rc = mfft_swap_axes(Y + (size_t)c * P * piece, out + (size_t)c * Rc * n1 * es, P, Rc, W, p->dtype, s);
-        if (rc) return rc;
+        MFFT_HIP(hipStreamWaitEvent(s, back[(size_t)c], 0));
+        MFFT_TRY(mfft_swap_axes_strided(Y + (size_t)c * Rc * Wc * es, out + (size_t)c * Rc * n1 * es, (int64_t)P * G, Rc, Wc,
+                                        R * Wc, Wc, p->dtype, s));
     }
     return MFFT_OK;
 }
 
-// 1-D four-step on this rank's n/P consecutive samples
+// 1-D four-step on this rank's n/P consecutive samples: x[j1*n2 + j2], X[k1 + n1*k2].
+//
+// The n2 columns j2 are cut into P*G segments of Wc columns; rank q transforms segment g*P + q as its group g.
+//   pack      group g of local row i, [q][i][w] = x[i*n2 + (g*P + q)*Wc + w]: one strided block copy
+//   exchange  group-major; the first group in row chunks, packed and sent one after the other
+//   columns   the n1-point transforms of group g (inter-step twiddle folded into their last store) run while
+//             group g + 1 travels; their rows k1 in [q*R1, (q+1)*R1) belong to rank q, are contiguous, and
+//             leave while group g + 1 is transformed -- into the region group g arrived in, so sample j2 of
+//             local row i ends up at [j2 / Wc][i][j2 % Wc], a plain segmented layout
+//   rows      the last group travels in row chunks; the n2-point transforms of a chunk's rows read the
+//             segments in place while the next chunk is on the links
+//   natural   bin k2 of row i goes to [k2 / W2][i][k2 % W2] (the owner of natural index k2*n1 + k1); a
+//             chunk leaves for its owners while the next one is transformed; one transpose at the end
 static int exec_1d(DistPlan* p, const char* in, char* out, hipStream_t s)
 {
     Comm& cm = *p->comm;
-    const int P = cm.world, C = p->chunks;
-    const int64_t n1 = p->a0, n2 = p->a1, R1 = n1 / P, W2 = n2 / P, Rc = R1 / C;
+    const int P = cm.world, C = p->chunks, G = p->groups;
+    const int64_t n1 = p->a0, n2 = p->a1, R1 = n1 / P, W2 = n2 / P, Rc = R1 / C, Wc = W2 / G;
     const size_t es = elem_size(p->dtype);
     char* X = static_cast<char*>(p->buf[0]);
     char* Y = static_cast<char*>(p->buf[1]);
+    hipStream_t sc = p->s_comm;
     std::vector<const void*> snd;
     std::vector<void*> rcv;
-    int rc;
-    const size_t piece = (size_t)Rc * W2 * es;                  // one (chunk, peer) block
-    const char* cur = in;
-    MFFT_HIP(hipEventRecord(p->arrived(C), s));
-    MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->arrived(C), 0));
-    if (P > 1) {
-        // pack: local rows j1 (Rc x P x W2 per chunk) -> [q][i][c]; rank q owns columns [q*W2, (q+1)*W2)
-        for (int c = 0; c < C; ++c) {
-            const size_t chunk = (size_t)c * (size_t)Rc * (size_t)n2 * es;
-            rc = mfft_swap_axes(in + chunk, X + chunk, Rc, P, W2, p->dtype, s);
-            if (rc) return rc;
-            MFFT_HIP(hipEventRecord(p->produced(c), s));
-            MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->produced(c), 0));
-            block_ptrs(&snd, &rcv, P, X + chunk, piece, 0, Y, (size_t)R1 * W2 * es, (size_t)c * piece);
-            rc = cm.exchange(snd.data(), rcv.data(), piece, p->s_comm);
-            if (rc) return rc;
-        }
-        MFFT_HIP(hipEventRecord(p->arrived(0), p->s_comm));
-        MFFT_HIP(hipStreamWaitEvent(s, p->arrived(0), 0));
-        cur = Y;                                                // (n1 x W2): cur[j1][c] = x[j1*n2 + rank*W2 + c]
-    }
-    // n1-point transforms on the strided columns, inter-step twiddle W_n^(k1 * (rank*W2 + c)) folded
-    // into their last store:  X[k1][c]
-    rc = mfft_exec(p->cols, cur, X, 1.0, 0.0, 0.0, 1.0, nullptr, s);
-    if (rc) return rc;
-    // Second exchange + n2-point transforms, chunked over this rank's rows k1: the blocks of chunk c
-    // (rows [c*Rc, +Rc) from every peer, landing at [q][i][:]) are transformed while chunk c + 1
-    // travels.  Sample j2 of local row i sits at [j2 / W2][i][j2 % W2].
-    // natural order: bin k2 of row i goes to [k2 / W2][i][k2 % W2] of `Z` (the owner of natural index
-    // k2*n1 + k1), and chunk c leaves for its owners -- into the very regions of Y that chunk c of the
-    // second exchange occupied and the transform has just consumed -- while chunk c + 1 is transformed.
     const bool natural = p->option != 0;
-    const char* rows_in = X;
-    if (P > 1) {
-        MFFT_HIP(hipEventRecord(p->produced(0), s));
-        MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->produced(0), 0));
-        rows_in = Y;
+    p->ev_next = 0;
+    if (P == 1) {
+        MFFT_TRY(mfft_exec(p->col_plan(0), in, X, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        if (!natural) return mfft_exec(p->rows, X, out, 1.0, 0.0, 0.0, 1.0, nullptr, s);     // out[i*n2 + k2] = X[i + n1*k2]
+        MFFT_TRY(mfft_exec(p->rows, X, Y, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        return mfft_transpose(Y, out, n1, n2, 1, p->dtype, s);
     }
-    char* Z = natural ? (P > 1 ? out : Y) : out;
-    // Order on the exchange stream: second-exchange chunk c + 1 is enqueued before the wait for the
-    // transform of chunk c, so it travels during that transform, and third-exchange chunk c travels
-    // during the transform of chunk c + 1.  Every rank enqueues the same sequence.
-    const auto second_exchange = [&](int c) -> int {
-        block_ptrs(&snd, &rcv, P, X, (size_t)R1 * W2 * es, (size_t)c * piece, Y, (size_t)R1 * W2 * es, (size_t)c * piece);
-        const int e = cm.exchange(snd.data(), rcv.data(), piece, p->s_comm);
-        if (e) return e;
-        MFFT_HIP(hipEventRecord(p->arrived(c), p->s_comm));
-        return MFFT_OK;
-    };
-    if (P > 1) {
-        rc = second_exchange(0);
-        if (rc) return rc;
-    }
-    for (int c = 0; c < C; ++c) {
-        if (P > 1) {
-            if (c + 1 < C) {
-                rc = second_exchange(c + 1);
-                if (rc) return rc;
+    const size_t blk = (size_t)R1 * Wc * es;                   // one (peer, group) block
+    const size_t gsz = (size_t)P * blk;                        // one group's (n1 x Wc) column matrix
+    MFFT_TRY(p->link(s, sc));
+    std::vector<hipEvent_t> here((size_t)G), landed((size_t)C);
+    for (int g = 0; g < G; ++g) {
+        const int nck = g == 0 ? C : 1;
+        const int64_t rows = R1 / nck;
+        const size_t piece = blk / nck;
+        for (int c = 0; c < nck; ++c) {
+            char* pack = X + (size_t)g * gsz + (size_t)c * P * piece;          // [q][i][w], P x rows x Wc
+            MFFT_TRY(mfft_swap_axes_strided(in + ((size_t)c * rows * n2 + (size_t)g * P * Wc) * es, pack, rows, P, Wc, n2, Wc, p->dtype, s));
+            MFFT_TRY(p->link(s, sc));
+            snd.resize((size_t)P); rcv.resize((size_t)P);
+            for (int q = 0; q < P; ++q) {
+                snd[(size_t)q] = pack + (size_t)q * piece;
+                rcv[(size_t)q] = Y + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;       // rows j1 = q*R1 + c*rows + i
             }
-            MFFT_HIP(hipStreamWaitEvent(s, p->arrived(c), 0));
+            MFFT_TRY(cm.exchange(snd.data(), rcv.data(), piece, sc));
         }
-        // chunk c: signals i in [c*Rc, +Rc); in a segmented buffer signal i starts at i*W2
-        const size_t seg_off = (size_t)c * piece;
-        const size_t dense_off = (size_t)c * (size_t)Rc * (size_t)n2 * es;
-        rc = mfft_exec(p->rows, rows_in + (P > 1 ? seg_off : dense_off), Z + ((natural && P > 1) ? seg_off : dense_off),
-                       1.0, 0.0, 0.0, 1.0, nullptr, s);
-        if (rc) return rc;
-        if (natural && P > 1) {
-            MFFT_HIP(hipEventRecord(p->produced(c), s));
-            MFFT_HIP(hipStreamWaitEvent(p->s_comm, p->produced(c), 0));
-            block_ptrs(&snd, &rcv, P, Z, (size_t)R1 * W2 * es, (size_t)c * piece, Y, (size_t)R1 * W2 * es, (size_t)c * piece);
-            rc = cm.exchange(snd.data(), rcv.data(), piece, p->s_comm);
-            if (rc) return rc;
+        MFFT_TRY(p->mark(sc, &here[(size_t)g]));
+    }
+    for (int g = 0; g < G; ++g) {
+        MFFT_HIP(hipStreamWaitEvent(s, here[(size_t)g], 0));
+        MFFT_TRY(mfft_exec(p->col_plan(g), Y + (size_t)g * gsz, X + (size_t)g * gsz, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        MFFT_TRY(p->link(s, sc));
+        const int nck = g == G - 1 ? C : 1;
+        const size_t piece = blk / nck;
+        for (int c = 0; c < nck; ++c) {
+            snd.resize((size_t)P); rcv.resize((size_t)P);
+            for (int q = 0; q < P; ++q) {
+                snd[(size_t)q] = X + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;
+                rcv[(size_t)q] = Y + (size_t)g * gsz + (size_t)q * blk + (size_t)c * piece;       // [segment g*P + q][row][w]
+            }
+            MFFT_TRY(cm.exchange(snd.data(), rcv.data(), piece, sc));
+            if (g == G - 1) MFFT_TRY(p->mark(sc, &landed[(size_t)c]));
         }
+    }
+    // Every send out of X has been enqueued before the first receive into it below, and the exchange stream
+    // runs in order: X is free for the natural-order exchange to land in.
+    const size_t run = (size_t)Rc * W2 * es;                   // a chunk's rows within one peer's (R1 x W2) block
+    for (int c = 0; c < C; ++c) {
+        MFFT_HIP(hipStreamWaitEvent(s, landed[(size_t)c], 0));
+        if (!natural) {
+            MFFT_TRY(mfft_exec(p->rows, Y + (size_t)c * Rc * Wc * es, out + (size_t)c * Rc * n2 * es, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+            continue;
+        }
+        MFFT_TRY(mfft_exec(p->rows, Y + (size_t)c * Rc * Wc * es, out + (size_t)c * run, 1.0, 0.0, 0.0, 1.0, nullptr, s));
+        MFFT_TRY(p->link(s, sc));
+        snd.resize((size_t)P); rcv.resize((size_t)P);
+        for (int q = 0; q < P; ++q) {
+            snd[(size_t)q] = out + (size_t)q * R1 * W2 * es + (size_t)c * run;
+            rcv[(size_t)q] = X + (size_t)q * R1 * W2 * es + (size_t)c * run;
+        }
+        MFFT_TRY(cm.exchange(snd.data(), rcv.data(), run, sc));
     }
     if (!natural) return MFFT_OK;                               // out[i*n2 + k2] = X[(rank*R1 + i) + n1*k2]
-    if (P > 1) {
-        MFFT_HIP(hipEventRecord(p->arrived(0), p->s_comm));
-        MFFT_HIP(hipStreamWaitEvent(s, p->arrived(0), 0));
+    MFFT_TRY(p->link(sc, s));
+    // X[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: an (n1 x W2) matrix; its transpose is the natural-order chunk
+    return mfft_transpose(X, out, n1, W2, 1, p->dtype, s);
+}
+
+// Column-batched plans of one group, retried with fewer groups while the tile passes do not serve the width.
+// make(g_count, g_index, &plan) builds one plan; `per_group`: one plan per group (else one plan serves all).
+template <class Make>
+static int build_col_plans(DistPlan* p, int requested, int64_t cols, bool per_group, Make make)
+{
+    int g = group_count(requested, cols, p->comm->world, p->dtype);
+    for (;;) {
+        int rc = MFFT_OK;
+        const int count = per_group ? g : 1;
+        p->cols.assign((size_t)count, nullptr);
+        for (int i = 0; i < count && rc == MFFT_OK; ++i) rc = make(g, i, &p->cols[(size_t)i]);
+        if (rc == MFFT_OK) { p->groups = g; return MFFT_OK; }
+        for (mfft_plan& c : p->cols) { if (c) (void)mfft_plan_destroy(c); c = nullptr; }
+        p->cols.clear();
+        if (rc != MFFT_E_UNSUPPORTED || g == 1) return rc;      // shapes the tile passes do not serve at all: MFFT_E_UNSUPPORTED
+        do { --g; } while (g > 1 && cols % g);
     }
-    // Y[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: an (n1 x W2) matrix; its transpose is the natural-order chunk
-    return mfft_transpose(Y, out, n1, W2, 1, p->dtype, s);
 }
 
 }  // namespace mfft
@@ -411,13 +501,20 @@ int mfft_comm_init_local(mfft_comm* out, int nranks)
     g->send.assign((size_t)nranks, nullptr);
     g->ready.assign((size_t)nranks, nullptr);
     g->done.assign((size_t)nranks, nullptr);
+    // on a failure part-way nothing is left behind: the handles made so far and the group's events are released
+    const auto undo = [&] {
+        for (int i = 0; i < nranks; ++i) { delete reinterpret_cast<Comm*>(out[i]); out[i] = nullptr; }
+        for (hipEvent_t e : g->ready) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : g->done) if (e) (void)hipEventDestroy(e);
+    };
     for (int i = 0; i < nranks; ++i) {
-        MFFT_HIP(hipEventCreateWithFlags(&g->ready[(size_t)i], hipEventDisableTiming));
-        MFFT_HIP(hipEventCreateWithFlags(&g->done[(size_t)i], hipEventDisableTiming));
+        hipError_t e = hipEventCreateWithFlags(&g->ready[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done[(size_t)i], hipEventDisableTiming);
+        if (e != hipSuccess) { undo(); return hip_fail(e, "hipEventCreateWithFlags", __FILE__, __LINE__); }
     }
     for (int i = 0; i < nranks; ++i) {
         Comm* c = new (std::nothrow) Comm;
-        if (!c) { set_error("host allocation failed"); return MFFT_E_NOMEM; }
+        if (!c) { undo(); set_error("host allocation failed"); return MFFT_E_NOMEM; }
         c->world = nranks; c->rank = i; c->device = device; c->local = true; c->group = g;
         out[i] = reinterpret_cast<mfft_comm>(c);
     }
@@ -473,7 +570,7 @@ static int dist_plan_begin(mfft_dist_plan* out, mfft_comm comm, int dtype, std::
 }
 
 int mfft_plan_2d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n0, int64_t n1, int dtype, int restore_layout,
-                      int chunks)
+                      int chunks, int col_groups)
 {
     std::unique_ptr<DistPlan> p;
     int rc = dist_plan_begin(out, comm, dtype, &p);
@@ -485,19 +582,23 @@ int mfft_plan_2d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n0, int64_t n
     const int64_t R = n0 / P, W = n1 / P;
     p->chunks = chunk_count(chunks, R, P);
     const int64_t Rc = R / p->chunks;
-    const mfft_layout lout{W, W, Rc * W};
+    rc = build_col_plans(p.get(), col_groups, W, false, [&](int g, int, mfft_plan* plan) {
+        // column slabs out: a group's columns are a block of the (n0 x W) result, rows W elements apart
+        return mfft_plan_1d_columns_ld(plan, n0, W / g, 1, dtype, 0, 0, restore_layout ? 0 : W);
+    });
+    if (rc) return rc;
+    const int64_t Wc = W / p->groups;
+    const mfft_layout lout{Wc, Wc, R * Wc};
     rc = mfft_plan_1d_layout(&p->rows, n1, n1, Rc, dtype, 0, nullptr, P > 1 ? &lout : nullptr);
     if (rc) return rc;
-    rc = mfft_plan_1d_columns(&p->cols, n0, W, 1, dtype, 0, 0);
-    if (rc) return rc;                 // shapes the tile passes do not serve: MFFT_E_UNSUPPORTED
-    rc = plan_common(p.get(), (size_t)R * (size_t)n1, p->chunks);
+    rc = plan_common(p.get(), (size_t)R * (size_t)n1);
     if (rc) return rc;
     *out = reinterpret_cast<mfft_dist_plan>(p.release());
     return MFFT_OK;
 }
 
 int mfft_plan_1d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n1, int64_t n2, int dtype, int natural_order,
-                      int chunks)
+                      int chunks, int col_groups)
 {
     std::unique_ptr<DistPlan> p;
     int rc = dist_plan_begin(out, comm, dtype, &p);
@@ -510,12 +611,18 @@ int mfft_plan_1d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n1, int64_t n
     const int64_t R1 = n1 / P, W2 = n2 / P;
     p->chunks = chunk_count(chunks, R1, P);
     const int64_t Rc = R1 / p->chunks;
-    rc = mfft_plan_1d_columns(&p->cols, n1, W2, 1, dtype, n1 * n2, (int64_t)p->comm->rank * W2);
+    const int rank = p->comm->rank;
+    rc = build_col_plans(p.get(), col_groups, W2, true, [&](int g, int i, mfft_plan* plan) {
+        // group i of this rank is column segment i*P + rank: its first column sets the fused twiddle
+        const int64_t wc = W2 / g;
+        return mfft_plan_1d_columns(plan, n1, wc, 1, dtype, n1 * n2, ((int64_t)i * P + rank) * wc);
+    });
     if (rc) return rc;
-    const mfft_layout seg{W2, W2, R1 * W2};
-    rc = mfft_plan_1d_layout(&p->rows, n2, n2, Rc, dtype, 0, P > 1 ? &seg : nullptr, (P > 1 && natural_order) ? &seg : nullptr);
+    const int64_t Wc = W2 / p->groups;
+    const mfft_layout seg_in{Wc, Wc, R1 * Wc}, seg_out{W2, W2, R1 * W2};
+    rc = mfft_plan_1d_layout(&p->rows, n2, n2, Rc, dtype, 0, P > 1 ? &seg_in : nullptr, (P > 1 && natural_order) ? &seg_out : nullptr);
     if (rc) return rc;
-    rc = plan_common(p.get(), (size_t)R1 * (size_t)n2, p->chunks);
+    rc = plan_common(p.get(), (size_t)R1 * (size_t)n2);
     if (rc) return rc;
     *out = reinterpret_cast<mfft_dist_plan>(p.release());
     return MFFT_OK;
@@ -537,11 +644,12 @@ int mfft_dist_exec(mfft_dist_plan plan, const void* d_in, void* d_out, void* str
     return rc;
 }
 
-int mfft_dist_plan_info(mfft_dist_plan plan, int* chunks, int64_t* workspace_bytes)
+int mfft_dist_plan_info(mfft_dist_plan plan, int* chunks, int* col_groups, int64_t* workspace_bytes)
 {
-    if (!plan || !chunks || !workspace_bytes) { set_error("null argument"); return MFFT_E_INVALID; }
+    if (!plan || !chunks || !col_groups || !workspace_bytes) { set_error("null argument"); return MFFT_E_INVALID; }
     const DistPlan* p = reinterpret_cast<const DistPlan*>(plan);
     *chunks = p->chunks;
+    *col_groups = p->groups;
     *workspace_bytes = (int64_t)(2 * p->local_bytes);
     return MFFT_OK;
 }

@@ -180,18 +180,21 @@ __global__ void seg_copy_kernel(const E* src, E* dst, int64_t batch, int64_t cou
     }
 }
 
-// out[b][a][:] = in[a][b][:] for an (A, B, W) array of complex elements: one row of W
-// contiguous elements per loop trip, copied 16 bytes per lane where W allows
+// out[b][a][:] = in[a*sa + b*sb + (0..W)] for complex elements (sa = B*W, sb = W: an (A, B, W) array with
+// its two leading axes swapped): one row of W contiguous elements per loop trip, copied 16 bytes per
+// lane where W and the strides allow
 template <typename T>
-__global__ void swap_axes_kernel(const cx<T>* in, cx<T>* out, int64_t A, int64_t B, int64_t W)
+__global__ void swap_axes_kernel(const cx<T>* in, cx<T>* out, int64_t A, int64_t B, int64_t W, int64_t sa, int64_t sb)
 {
     constexpr int PER16 = 16 / (int)sizeof(cx<T>);            // elements per 16-byte unit
     const int64_t rows = A * B;
+    const bool wide = W % PER16 == 0 && sa % PER16 == 0 && sb % PER16 == 0 &&
+                      (reinterpret_cast<size_t>(in) & 15) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const int64_t a = row / B, b = row - a * B;
-        const cx<T>* src = in + row * W;
+        const cx<T>* src = in + a * sa + b * sb;
         cx<T>* dst = out + (b * A + a) * W;
-        if (W % PER16 == 0) {
+        if (wide) {
             using V4 = float __attribute__((ext_vector_type(4)));
             const V4* s4 = reinterpret_cast<const V4*>(src);
             V4* d4 = reinterpret_cast<V4*>(dst);

@@ -534,7 +534,6 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     using C = cx<T>;
     constexpr int N = RD::n;
     constexpr int TX = N / P;
-    constexpr int LOG2TX = __builtin_ctz(TX);
     constexpr int SLOTS = BLOCK / TX;
     constexpr int NPASS = RD::npass;
     constexpr int LDS_ELEMS = ((lds_pad<PADSHIFT>(N - 1) + 1 + 1) / 2) * 2;   // keep slots 16-byte aligned
@@ -606,15 +605,14 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         const int64_t bl = bsig < a.batch ? bsig : a.batch - 1;
         if constexpr (VAR == V_SEG) {
             const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bl * a.in_stride;
-            // segments hold a whole number of TX-element rows (seg = TX << q), so the segment of
-            // element t + TX*e is e >> q for every lane: the offsets are wave-uniform (scalar
-            // registers) and one lane-dependent address serves all P accesses
-            const int q = a.in_lseg - LOG2TX;
+            // Element j = t + TX*e sits at (j >> lseg) * seg_stride + (j & (seg - 1)).  Segments are powers
+            // of two of at least one wave's 64 elements, so either a segment holds whole TX-element rows or
+            // a row holds whole segments: no carry between t and TX*e, and the position splits into a
+            // lane part (from t) and a part that depends on e and the kernel arguments only -- wave-uniform
+            // (scalar registers), so one lane-dependent address serves all P accesses
+            const C* __restrict__ lane = src + seg_pos(t, a.in_lseg, a.in_seg_stride);
 #pragma unroll
-            for (int e = 0; e < P; ++e) {
-                const int64_t off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
-                dst[e] = ld_stream(src + off + t);
-            }
+            for (int e = 0; e < P; ++e) dst[e] = ld_stream(lane + seg_pos(TX * e, a.in_lseg, a.in_seg_stride));
         } else if constexpr (VAR == V_REAL) {
             const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + bl * a.in_stride;
 #pragma unroll
@@ -650,16 +648,12 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     const auto dma_signal = [&](int64_t bsig) {
         const C* __restrict__ src = reinterpret_cast<const C*>(a.in) + bsig * a.in_stride;      // wave-uniform
         const uint32_t lane_off = (threadIdx.x & 63u) * 16u;
-        const int q = a.in_lseg - LOG2TX;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wv + NW * i;
             const int j0 = piece * PE;
             int64_t off = j0;
-            if constexpr (VAR == V_SEG) {
-                const int e = j0 >> LOG2TX;
-                off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
-            }
+            if constexpr (VAR == V_SEG) off = seg_pos(j0, a.in_lseg, a.in_seg_stride);     // a piece lies inside one segment (seg >= PE)
             dma_1k(src + off, lane_off, stage_lds + (uint32_t)piece * 1024u);
         }
     };
@@ -680,10 +674,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         for (int k = 0; k < PPW / 8; ++k) {
             const int j0 = (wv + NW * (8 * k + (int)(lane >> 3))) * PE;       // first element of the lane's piece
             int64_t off = j0;
-            if constexpr (VAR == V_SEG) {
-                const int q = a.in_lseg - LOG2TX, e = j0 >> LOG2TX;
-                off = (int64_t)(e >> q) * a.in_seg_stride + (int64_t)TX * (e & ((1 << q) - 1)) + (j0 & (TX - 1));
-            }
+            if constexpr (VAR == V_SEG) off = seg_pos(j0, a.in_lseg, a.in_seg_stride);
             dma_touch(reinterpret_cast<const char*>(src + off) + (lane & 7u) * 128u, stage_lds + (uint32_t)DMA_WARM_AT + (uint32_t)wv * 256u);
         }
     };
@@ -1019,24 +1010,22 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     // offset register serves all P stores and no vector instruction is spent on addresses
                     const uint32_t voff = (uint32_t)tl * (uint32_t)sizeof(C);
                     if constexpr (VAR == V_SEG) {
-                        const int q = a.out_lseg - LOG2TX;
+                        // lane part of the position as the 32-bit buffer offset (launch_one checks that a row's
+                        // segments span less than 4 GiB), the e part in the descriptor's base
+                        const uint32_t vseg = (uint32_t)seg_pos(tl, a.out_lseg, a.out_seg_stride) * (uint32_t)sizeof(C);
+                        const uint32_t span = ((uint32_t)seg_pos(TX - 1, a.out_lseg, a.out_seg_stride) + 1u) * (uint32_t)sizeof(C);
 #pragma unroll
-                        for (int e = 0; e < P; ++e) {
-                            const int64_t off = (int64_t)(e >> q) * a.out_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
-                            buf_st<C, MFFT_NT ? 2 : 0>(make_rsrc_uniform(dst + off, (uint32_t)TX * sizeof(C)), voff, 0u, v[e]);
-                        }
+                        for (int e = 0; e < P; ++e)
+                            buf_st<C, MFFT_NT ? 2 : 0>(make_rsrc_uniform(dst + seg_pos(TX * e, a.out_lseg, a.out_seg_stride), span), vseg, 0u, v[e]);
                     } else {
                         const auto ro = make_rsrc_uniform(dst, (uint32_t)N * sizeof(C));
 #pragma unroll
                         for (int e = 0; e < P; ++e) buf_st<C, MFFT_NT ? 2 : 0>(ro, voff, TX * e * sizeof(C), v[e]);
                     }
                 } else if constexpr (VAR == V_SEG) {
-                    const int q = a.out_lseg - LOG2TX;
+                    C* __restrict__ lane = dst + seg_pos(tl, a.out_lseg, a.out_seg_stride);
 #pragma unroll
-                    for (int e = 0; e < P; ++e) {
-                        const int64_t off = (int64_t)(e >> q) * a.out_seg_stride + (int64_t)TX * (e & ((1 << q) - 1));
-                        st_stream(dst + off + tl, v[e]);
-                    }
+                    for (int e = 0; e < P; ++e) st_stream(lane + seg_pos(TX * e, a.out_lseg, a.out_seg_stride), v[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < P; ++e) st_stream(dst + tl + TX * e, v[e]);
@@ -1176,7 +1165,10 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
     constexpr int BLOCK = BlockCfg<T, LOG2N, VAR>::BLOCK;
     constexpr int SLOTS = BLOCK / BlockCfg<T, LOG2N, VAR>::TX;
     if constexpr (!DMA && dma_default<T, (1 << LOG2N), VAR>()) {
-        if (dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
+        // (segmented stores of the pipeline address a row's segments through one 32-bit offset)
+        constexpr int TXK = BlockCfg<T, LOG2N, VAR>::TX;
+        const bool span_ok = VAR != V_SEG || ((uint64_t)(seg_pos(TXK - 1, a.out_lseg, a.out_seg_stride) + 1) * sizeof(cx<T>) < (uint64_t(1) << 32));
+        if (span_ok && dma_usable<T, VAR>(a)) return launch_one<T, LOG2N, VAR, true>(a, grid, s);
     }
     constexpr int LDS_ELEMS = ((lds_pad<kPadShift>((1 << LOG2N) - 1) + 1 + 1) / 2) * 2;
     constexpr size_t lds = DMA ? ((size_t)SLOTS * LDS_ELEMS + twc_total_elems<typename SC::RD>()) * sizeof(cx<T>) + (MFFT_DMA_WARM != 0 ? BLOCK * 4 : 0) + (BLOCK / 64) * 24

@@ -199,6 +199,7 @@ struct Pow2Engine {
     bool table_window = false;          // MFFT_TABLE_WINDOW at build: windowed first passes read the window table (tuning aid)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
+    int64_t out_ld = 0;                 // column-batched: elements between rows of the result (0 = inner, dense)
 
     int build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_ = 1, int64_t fs_n_ = 0, int64_t fs_c0_ = 0);
     void release();
@@ -416,10 +417,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
                           io.in_seg == 0 && io.out_seg == 0;
         const bool bare_or_stats = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && full;
         const bool bare = bare_or_stats && !io.stats;
-        // V_SEG: power-of-two segments of at least n/P elements (P = points per thread), at most 2^30
-        const int64_t seg_min = n / geo.p;
-        const auto seg_fast = [&](int64_t sg) { return sg == 0 || (is_pow2(sg) && sg >= seg_min && sg <= (int64_t(1) << 30)); };
-        const bool seg_ok = seg_fast(io.in_seg) && seg_fast(io.out_seg);
+        const bool seg_ok = seg_is_fast(io.in_seg, n, geo.p, dtype) && seg_is_fast(io.out_seg, n, geo.p, dtype);
         const bool bare_seg = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && !io.stats &&
                               !io.win && !io.power && io.n_in == n && io.n_out == n && seg_ok;
         int variant;
@@ -514,6 +512,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.in_stride = src_stride;
         a.out = last ? io.out : (via_out ? (((np - 1 - p) & 1) ? work[0] : io.out) : work[p & 1]);
         a.out_stride = last ? io.out_stride : nn;
+        a.out_pitch = (last && out_ld > 0) ? out_ld : inner;
         a.tw = static_cast<const cx<T>*>(gp.d_tw);
         a.tw_lo = static_cast<const cx<double>*>(gp.d_lo);
         a.tw_hi = static_cast<const cx<double>*>(gp.d_hi);
@@ -750,11 +749,10 @@ static bool plan_shares_state(const Plan* p)
     if (p->kind != Plan::POW2 && p->kind != Plan::COLUMNS) return false;
     if (!p->eng.single) return true;
     if (p->lin.seg == 0 && p->lout.seg == 0) return false;
-    // segmented: only the plain transform over power-of-two segments of at least n / (points per thread)
-    // elements runs without staging (V_SEG in Pow2Engine::exec)
-    const int64_t seg_min = p->n / p->eng.geo.p;
-    const auto fast = [&](int64_t sg) { return sg == 0 || (is_pow2(sg) && sg >= seg_min && sg <= (int64_t(1) << 30)); };
-    return !(p->flags == 0 && p->n_in == p->n && fast(p->lin.seg) && fast(p->lout.seg));
+    // segmented: only the plain transform over the segments seg_is_fast() names runs without staging
+    // (V_SEG in Pow2Engine::exec)
+    return !(p->flags == 0 && p->n_in == p->n && seg_is_fast(p->lin.seg, p->n, p->eng.geo.p, p->dtype) &&
+             seg_is_fast(p->lout.seg, p->n, p->eng.geo.p, p->dtype));
 }
 
 static int plan_build(Plan* p)
@@ -848,7 +846,8 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
         if (scale != 1.0) { set_error("column-batched plans do not scale their output"); return MFFT_E_INVALID; }
         Io<T> io;
         io.in = d_in; io.out = d_out;
-        io.in_stride = io.out_stride = p->n * p->inner;
+        io.in_stride = p->n * p->inner;
+        io.out_stride = p->n * (p->eng.out_ld > 0 ? p->eng.out_ld : p->inner);
         io.n_in = io.n_out = p->n;
         io.batch = slab;
         return p->eng.exec<T>(io, s);
@@ -1157,6 +1156,12 @@ int mfft_plan_1d(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, int dty
 int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
                          int64_t twiddle_n, int64_t twiddle_c0)
 {
+    return mfft_plan_1d_columns_ld(out, n, inner, batch, dtype, twiddle_n, twiddle_c0, 0);
+}
+
+int mfft_plan_1d_columns_ld(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
+                            int64_t twiddle_n, int64_t twiddle_c0, int64_t out_ld)
+{
     if (!out) { set_error("null plan pointer"); return MFFT_E_INVALID; }
     *out = nullptr;
     if (n < 1) { set_error("Invalid number of FFT data points (" + std::to_string(n) + ") specified."); return MFFT_E_INVALID; }
@@ -1173,6 +1178,16 @@ int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch
     p->kind = Plan::COLUMNS;
     p->n = n; p->n_in = n; p->batch = batch; p->dtype = dtype; p->flags = 0;
     p->inner = inner; p->fs_n = twiddle_n; p->fs_c0 = twiddle_c0;
+    if (out_ld == inner) out_ld = 0;
+    if (out_ld != 0) {
+        // rows of the result out_ld elements apart: the plain last pass only, 32-bit row offsets inside a tile
+        if (out_ld < inner || twiddle_n > 1 || n > (int64_t(1) << 32) / out_ld) {
+            delete p;
+            set_error("out_ld must be >= inner with n * out_ld <= 2^32, and excludes the fused twiddle");
+            return out_ld < inner ? MFFT_E_INVALID : MFFT_E_UNSUPPORTED;
+        }
+        p->eng.out_ld = out_ld;
+    }
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("hipGetDevice failed"); return MFFT_E_HIP; }
     const int rc = plan_build(p);
     if (rc != MFFT_OK) { plan_free(p); return rc; }
@@ -1219,7 +1234,7 @@ int mfft_exec_host(mfft_plan plan, const void* h_in, void* h_out, double scale, 
     Plan* p = reinterpret_cast<Plan*>(plan);
     if ((p->flags & MFFT_STATS) && !h_stats) { set_error("plan has MFFT_STATS but h_stats is null"); return MFFT_E_INVALID; }
     if (!h_out && !(p->flags & MFFT_STATS)) { set_error("h_out may be null only when the plan returns stats"); return MFFT_E_INVALID; }
-    if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg) {
+    if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg || p->eng.out_ld > 0) {
         set_error("mfft_exec_host serves dense layouts only; use mfft_exec for strided / segmented plans");
         return MFFT_E_UNSUPPORTED;
     }
@@ -1751,9 +1766,10 @@ int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, in
     return MFFT_OK;
 }
 
-int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int dtype, void* stream)
+int mfft_swap_axes_strided(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int64_t in_stride_a,
+                           int64_t in_stride_b, int dtype, void* stream)
 {
-    if (!d_in || !d_out || a < 1 || b < 1 || w < 1 || d_in == d_out) { set_error("bad argument"); return MFFT_E_INVALID; }
+    if (!d_in || !d_out || a < 1 || b < 1 || w < 1 || d_in == d_out || in_stride_a < 0 || in_stride_b < 0) { set_error("bad argument"); return MFFT_E_INVALID; }
     if (dtype != MFFT_C64 && dtype != MFFT_C128) { set_error("bad dtype"); return MFFT_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = a * b;
@@ -1763,12 +1779,18 @@ int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t 
     const unsigned grid = (unsigned)(rows < cap ? rows : cap);
     if (dtype == MFFT_C64)
         hipLaunchKernelGGL(swap_axes_kernel<float>, dim3(grid), dim3(block), 0, s, static_cast<const cx<float>*>(d_in),
-                           static_cast<cx<float>*>(d_out), a, b, w);
+                           static_cast<cx<float>*>(d_out), a, b, w, in_stride_a, in_stride_b);
     else
         hipLaunchKernelGGL(swap_axes_kernel<double>, dim3(grid), dim3(block), 0, s, static_cast<const cx<double>*>(d_in),
-                           static_cast<cx<double>*>(d_out), a, b, w);
+                           static_cast<cx<double>*>(d_out), a, b, w, in_stride_a, in_stride_b);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
+}
+
+int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int dtype, void* stream)
+{
+    if (a < 1 || b < 1 || w < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
+    return mfft_swap_axes_strided(d_in, d_out, a, b, w, b * w, w, dtype, stream);
 }
 
 int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t c0, int64_t n_total,

@@ -101,6 +101,7 @@ template <typename T> struct TArgs {
     int64_t batch;
     int64_t in_stride;    // elements between signals in `in`
     int64_t out_stride;   // elements between signals in `out`
+    int64_t out_pitch;    // LAST_PLAIN: elements between consecutive rows of a column-batched result (W = dense; 1 for ordinary signals)
     int64_t n_in;         // FIRST: samples present per signal
     int64_t n_out;        // LAST: bins stored per signal
     int64_t in_seg, in_seg_stride;     // FIRST: segmented input layout (0 = dense)
@@ -608,10 +609,14 @@ fft_tile_kernel(const TArgs<T> a)
                 w = cmul(w, step);
             }
         } else if constexpr (MODE == TM_LAST_PLAIN) {
-            // last pass: NS*G = N, so j < NS and bin k = j + q*NS
-            C_* __restrict__ out_base = reinterpret_cast<C_*>(a.out) + b * a.out_stride + j0;
-            const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)a.NS;
-            const int64_t qstep = (int64_t)TX * a.NS;
+            // last pass: NS*G = N, so j < NS and bin k = j + q*NS.  Column-batched plans may store rows of
+            // the (n x W) result out_pitch elements apart (a column block of a wider array): row k of the
+            // result is (j >> log2_w) + q * (NS >> log2_w), its column j & (W - 1); out_pitch = W is dense
+            const int64_t nso = (a.NS >> a.log2_w) * a.out_pitch;
+            C_* __restrict__ out_base = reinterpret_cast<C_*>(a.out) + b * a.out_stride + (j0 >> a.log2_w) * a.out_pitch +
+                                        (j0 & ((int64_t(1) << a.log2_w) - 1));
+            const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)nso;
+            const int64_t qstep = (int64_t)TX * nso;
             if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) tile_st<T, false>(out_base + e * qstep + lane_out, v[e]);

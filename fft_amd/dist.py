@@ -201,21 +201,27 @@ class CComm:
         _lib.check(_lib.load().mfft_comm_init_local(arr, int(nranks)))
         return [cls(ctypes.c_void_p(arr[i]), nranks, i) for i in range(int(nranks))]
 
-    def plan(self, kind, a0, a1, dtype, option, chunks):
-        key = (kind, int(a0), int(a1), int(dtype), int(bool(option)), chunks)
+    def plan(self, kind, a0, a1, dtype, option, chunks, col_groups=None):
+        key = (kind, int(a0), int(a1), int(dtype), int(bool(option)), chunks, col_groups)
         h = self._plans.get(key)
         if h is None:
             h = ctypes.c_void_p()
             fn = _lib.load().mfft_plan_2d_dist if kind == "2d" else _lib.load().mfft_plan_1d_dist
             _lib.check(fn(ctypes.byref(h), self._h, int(a0), int(a1), int(dtype), int(bool(option)),
-                          int(chunks) if chunks else 0))
+                          int(chunks) if chunks else 0, int(col_groups) if col_groups else 0))
             self._plans[key] = h
         return h
 
-    def run(self, kind, src, a0, a1, option, chunks):
+    def plan_info(self, h):
+        """(row chunks, column groups, workspace bytes) of a distributed plan"""
+        ch, gr, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        _lib.check(_lib.load().mfft_dist_plan_info(h, ctypes.byref(ch), ctypes.byref(gr), ctypes.byref(ws)))
+        return ch.value, gr.value, ws.value
+
+    def run(self, kind, src, a0, a1, option, chunks, col_groups=None):
         import torch
         dtype = HipOps._dtype_of(src)
-        h = self.plan(kind, a0, a1, dtype, option, chunks)
+        h = self.plan(kind, a0, a1, dtype, option, chunks, col_groups)
         out = torch.empty_like(src)
         _lib.check(_lib.load().mfft_dist_exec(h, src.data_ptr(), out.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream or None))
@@ -268,24 +274,33 @@ class HipOps:
                 self._plans[key] = plan
         plan.exec(src, dst, stream=self._stream())
 
-    def _column_plan(self, n, inner, batch, dtype, twiddle, device):
-        key = ("col", n, inner, batch, dtype, twiddle, device)
+    def _column_plan(self, n, inner, batch, dtype, twiddle, device, out_ld=None):
+        if out_ld == inner:
+            out_ld = None
+        key = ("col", n, inner, batch, dtype, twiddle, device, out_ld)
         with self._lock:
             if key not in self._plans:
                 try:
-                    self._plans[key] = ColumnPlan(n, inner, batch=batch, dtype=dtype, twiddle=twiddle)
+                    self._plans[key] = ColumnPlan(n, inner, batch=batch, dtype=dtype, twiddle=twiddle, out_ld=out_ld)
                 except _lib.MfftError:
                     self._plans[key] = None          # shape outside the tile passes' range
             return self._plans[key]
 
-    def columns_ok(self, n, inner, like, batch=1):
-        """Whether fft_columns serves an (n x inner) array of this dtype."""
-        return self._column_plan(n, inner, batch, self._dtype_of(like), None, like.device.index) is not None
+    @staticmethod
+    def min_group_cols(like):
+        """Narrowest column group of the pipelined schedules: the shortest segments the contiguous-axis
+        kernels read and write in place (64 complex128 / 128 complex64 elements)."""
+        return 64 if HipOps._dtype_of(like) == _lib.C128 else 128
 
-    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None):
+    def columns_ok(self, n, inner, like, batch=1, out_ld=None):
+        """Whether fft_columns serves an (n x inner) array of this dtype."""
+        return self._column_plan(n, inner, batch, self._dtype_of(like), None, like.device.index, out_ld) is not None
+
+    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None, out_ld=None):
         """dst[b][k][c] = sum_j src[b][j][c] exp(-2 pi i j k / n), times exp(-2 pi i k (c0 + c) / n_total)
-        when twiddle = (n_total, c0); the columns are transformed where they lie."""
-        plan = self._column_plan(n, inner, batch, self._dtype_of(src), twiddle, src.device.index)
+        when twiddle = (n_total, c0); the columns are transformed where they lie.  out_ld: elements
+        between consecutive rows of dst (default inner: dense)."""
+        plan = self._column_plan(n, inner, batch, self._dtype_of(src), twiddle, src.device.index, out_ld)
         if plan is None:
             raise _lib.MfftError(f"no column-batched plan for n={n}, inner={inner}")
         plan.exec(src, dst, stream=self._stream())
@@ -294,10 +309,12 @@ class HipOps:
         _lib.check(_lib.load().mfft_transpose(src.data_ptr(), dst.data_ptr(), rows, cols, batch,
                                               self._dtype_of(src), self._stream() or None))
 
-    def swap_axes(self, src, dst, a, b, w):
-        """dst viewed as (b, a, w) = src viewed as (a, b, w) with the two leading axes swapped."""
-        _lib.check(_lib.load().mfft_swap_axes(src.data_ptr(), dst.data_ptr(), a, b, w,
-                                              self._dtype_of(src), self._stream() or None))
+    def swap_axes(self, src, dst, a, b, w, strides=None):
+        """dst viewed as (b, a, w): dst[j][i][:] = src[i*sa + j*sb + (0..w)], (sa, sb) = strides
+        (default (b*w, w): src viewed as (a, b, w) with the two leading axes swapped)."""
+        sa, sb = strides if strides is not None else (b * w, w)
+        _lib.check(_lib.load().mfft_swap_axes_strided(src.data_ptr(), dst.data_ptr(), a, b, w, sa, sb,
+                                                      self._dtype_of(src), self._stream() or None))
 
     def twiddle(self, x, rows, cols, r0, c0, n_total):
         _lib.check(_lib.load().mfft_twiddle_tile(x.data_ptr(), rows, cols, r0, c0, n_total,
@@ -324,26 +341,56 @@ class _Buffers:
         raise RuntimeError("no free scratch buffer")
 
 
+def _group_count(requested, cols, world, floor):
+    """Column groups of the pipelined schedules: the largest divisor of this rank's `cols` columns not
+    above the request (default 4, MFFT_DIST_GROUPS overrides) that leaves groups of at least `floor`
+    columns; 1 for one rank."""
+    import os
+    if world == 1:
+        return 1
+    if requested is None:
+        requested = int(os.environ.get("MFFT_DIST_GROUPS", "4"))
+    g = max(1, min(int(requested), cols))
+    while g > 1 and (cols % g or cols // g < floor):
+        g -= 1
+    return g
+
+
+def _wait_all(handles):
+    for h in handles:
+        h.wait()
+
+
 # --------------------------------------------------------------------------- 2-D slab / pencil
 
-def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=None):
+def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=None, col_groups=None):
     """2-D forward DFT of an n0 x n1 array distributed by row slabs.
 
     ``a_local``: this rank's n0/P consecutive rows, flat complex tensor of (n0/P)*n1
     elements (row-major).  Returns a flat tensor of the same size:
 
-    * ``restore_layout=False`` (one all-to-all): the spectrum in column slabs, all n0 rows
+    * ``restore_layout=False`` (one exchange): the spectrum in column slabs, all n0 rows
       of this rank's n1/P columns -- out[k0*(n1/P) + c] = F[k0][rank*(n1/P) + c];
-    * ``restore_layout=True`` (two all-to-alls): the spectrum in the input's own row-slab
+    * ``restore_layout=True`` (two exchanges): the spectrum in the input's own row-slab
       layout -- out[i*n1 + k1] = F[rank*(n0/P) + i][k1].
 
-    Local passes over the slab: row FFTs (stored already packed per destination), then the
-    column FFTs on the strided columns where the exchange left them (no transpose), then --
-    only with P > 1 and restore_layout -- one block copy that unpacks the way back.
+    Schedule with several ranks (mfft_plan_2d_dist runs the same one inside libmfft.so).  The
+    columns are cut into P*G segments of Wc columns; rank q transforms, as its group g, segment
+    q*G + g (column slabs out: its columns must be one contiguous range) or g*P + q (row slabs
+    out: any assignment serves, and this one frees a group's buffers as soon as it has moved on).
 
-    With several ranks the first exchange is pipelined: the rows are transformed in `chunks`
-    groups, and a group's blocks travel (grouped point-to-point sends, each landing as a
-    contiguous row range of the column matrix) while the next group is transformed.
+    * rows: bin k of local row i is stored at [k // Wc][i][k % Wc], so every (peer, group) block is
+      contiguous; the rows are transformed in `chunks` chunks;
+    * first exchange, group-major: the first group's chunks leave as their rows are transformed,
+      the other groups follow whole;
+    * columns: a group that has arrived is transformed along the strided axis (no transpose) while
+      the next one travels -- straight into its column block of the result, or, with
+      ``restore_layout``, into the send buffer of the way back, which leaves while the next group
+      is transformed;
+    * unpack: the last group travels back in row chunks, and a chunk's rows are unpacked into the
+      result while the next chunk is on the links.
+
+    ``col_groups=1`` is the schedule that chunks by rows only.
     """
     P = comm.world
     if n0 % P or n1 % P:
@@ -352,56 +399,70 @@ def fft2_slab(a_local, n0, n1, comm: Comm, ops, restore_layout=False, chunks=Non
     if a_local.numel() != R * n1:
         raise ValueError("a_local has the wrong size for this rank's slab")
     if isinstance(comm, CComm):                    # the whole decomposition inside libmfft.so, RCCL exchanges
-        return comm.run("2d", a_local, n0, n1, restore_layout, chunks)
+        return comm.run("2d", a_local, n0, n1, restore_layout, chunks, col_groups)
     bufs = _Buffers(ops, R * n1, a_local)
+    X = bufs.free(a_local)
+    Y = bufs.free(X)
 
-    # row FFTs; bin k of local row i is stored at [k // W][i][k % W]: already packed per destination
-    x = bufs.free(a_local)
-    C = _chunk_count(chunks, R, P)
-    if C == 1:
-        ops.fft(a_local, x, n=n1, batch=R, out_layout=(W, W, R * W))
-        cur = comm.all_to_all(bufs.free(x), x, "rows->columns")     # cur[r][i][c]: (n0 x W), row r*R + i, local column c
-    else:
-        Rc = R // C
-        cur = bufs.free(x)
-        pending = []
-        for c in range(C):
-            sb = x[c * Rc * n1:(c + 1) * Rc * n1]  # this group's send buffer: [s][i][col], P x Rc x W
-            ops.fft(a_local[c * Rc * n1:(c + 1) * Rc * n1], sb, n=n1, batch=Rc, out_layout=(W, W, Rc * W))
-            sends = [sb[s * Rc * W:(s + 1) * Rc * W] for s in range(P)]
-            recvs = [cur[(r * R + c * Rc) * W:(r * R + (c + 1) * Rc) * W] for r in range(P)]
-            pending.append(comm.start_exchange(sends, recvs, f"rows->columns[{c}/{C}]"))
-        for h in pending:
-            h.wait()
-    nxt = bufs.free(cur)
-    if ops.columns_ok(n0, W, cur):
-        ops.fft_columns(cur, nxt, n=n0, inner=W)
-        cur = nxt
-    else:                                          # shapes outside the tile passes: go through a transpose
-        ops.transpose(cur, nxt, rows=n0, cols=W)   # (W x n0)
-        ops.fft(nxt, cur, n=n0, batch=W)
-        ops.transpose(cur, nxt, rows=W, cols=n0)   # (n0 x W)
-        cur = nxt
-    # cur[k0][c] = F[k0][rank*W + c]
-    if not restore_layout:
-        return cur
+    def columns(src, dst, wc, out_ld=None):
+        """n0-point transforms down the wc columns of src (n0 x wc) into dst (rows out_ld apart)"""
+        if ops.columns_ok(n0, wc, src, out_ld=out_ld):
+            ops.fft_columns(src, dst, n=n0, inner=wc, out_ld=out_ld)
+            return
+        assert wc == W and out_ld in (None, W)     # shapes outside the tile passes: one group, through a transpose
+        ops.transpose(src, X, rows=n0, cols=W)     # (W x n0)
+        ops.fft(X, src, n=n0, batch=W)
+        ops.transpose(src, dst, rows=W, cols=n0)   # (n0 x W)
+
     if P == 1:
-        return cur
-    # way back: rows [s*R, (s+1)*R) belong to rank s and are contiguous; they travel in row chunks, and
-    # a chunk that has arrived ([s][i][c], P x Rc x W) is unpacked into its Rc output rows while the
-    # next one is on the links
-    C2 = _chunk_count(chunks, R, P)
-    Rc, piece = R // C2, (R // C2) * W
-    res = bufs.free(cur)
+        ops.fft(a_local, Y, n=n1, batch=R)
+        out = ops.empty(R * n1, a_local)
+        columns(Y, out, W)
+        return out
+    G = _group_count(col_groups, W, P, ops.min_group_cols(a_local))
+    while G > 1 and not ops.columns_ok(n0, W // G, a_local, out_ld=None if restore_layout else W):
+        G -= 1
+        while G > 1 and W % G:
+            G -= 1
+    C = _chunk_count(chunks, R, P)
+    Rc, Wc = R // C, W // G
+    blk, gsz = R * Wc, P * R * Wc                  # one (peer, group) block; one group's (n0 x Wc) column matrix
+    seg_of = (lambda q, g: g * P + q) if restore_layout else (lambda q, g: q * G + g)
+
+    def unit(src_of, g, c, nck, label):
+        """exchange of chunk c (of nck) of group g: rows [c*R/nck, (c+1)*R/nck) of every (peer, group) block"""
+        piece = blk // nck
+        sends = [src_of(q)[c * piece:(c + 1) * piece] for q in range(P)]
+        recvs = [Y[g * gsz + q * blk + c * piece:g * gsz + q * blk + (c + 1) * piece] for q in range(P)]
+        return comm.start_exchange(sends, recvs, label)
+
+    arriving = {g: [] for g in range(G)}
+    for c in range(C):
+        ops.fft(a_local[c * Rc * n1:(c + 1) * Rc * n1], X[c * Rc * Wc:], n=n1, batch=Rc, out_layout=(Wc, Wc, R * Wc))
+        arriving[0].append(unit(lambda q: X[seg_of(q, 0) * blk:], 0, c, C, f"rows->columns[group 0/{G}, chunk {c}/{C}]"))
+    for g in range(1, G):
+        arriving[g].append(unit(lambda q, g=g: X[seg_of(q, g) * blk:], g, 0, 1, f"rows->columns[group {g}/{G}]"))
     out = ops.empty(R * n1, a_local)
-    pending = []
-    for c in range(C2):
-        sends = [cur[(s * R + c * Rc) * W:(s * R + c * Rc) * W + piece] for s in range(P)]
-        recvs = [res[(c * P + r) * piece:(c * P + r + 1) * piece] for r in range(P)]
-        pending.append(comm.start_exchange(sends, recvs, f"columns->rows[{c}/{C2}]"))
-    for c, h in enumerate(pending):
-        h.wait()
-        ops.swap_axes(res[c * P * piece:], out[c * Rc * n1:], a=P, b=Rc, w=W)     # out[i][s][c]: Rc rows of n1
+    back = []
+    for g in range(G):
+        _wait_all(arriving[g])
+        if not restore_layout:                     # out[k0][rank's column g*Wc + w]: rows W elements apart
+            columns(Y[g * gsz:(g + 1) * gsz], out[g * Wc:], Wc, out_ld=W)
+            continue
+        # group g's send blocks have left: their region takes the transformed group, whose rows
+        # [q*R, (q+1)*R) belong to rank q and are contiguous
+        columns(Y[g * gsz:(g + 1) * gsz], X[g * gsz:(g + 1) * gsz], Wc)
+        nck = C if g == G - 1 else 1
+        for c in range(nck):
+            h = unit(lambda q, g=g: X[g * gsz + q * blk:], g, c, nck, f"columns->rows[group {g}/{G}, chunk {c}/{nck}]")
+            back.append(h)
+    if not restore_layout:
+        return out
+    # Y[s][i][w] = F[rank*R + i][s*Wc + w]: out[i][s][w], Rc rows at a time as the last group's chunks arrive
+    _wait_all(back[:G - 1])
+    for c in range(C):
+        back[G - 1 + c].wait()
+        ops.swap_axes(Y[c * Rc * Wc:], out[c * Rc * n1:], a=P * G, b=Rc, w=Wc, strides=(R * Wc, Wc))
     return out
 
 
@@ -417,7 +478,7 @@ def fourstep_factors(log2n: int, complex128: bool = True):
 
 # --------------------------------------------------------------------------- large 1-D four-step
 
-def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=None):
+def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=None, col_groups=None):
     """Forward DFT of ONE signal of n = n1*n2 points distributed in contiguous chunks.
 
     ``x_local``: this rank's n/P consecutive samples (flat complex tensor).  With
@@ -427,14 +488,24 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
 
     Returns a flat tensor of n/P elements:
 
-    * ``natural_order=True`` (three all-to-alls): X[rank*n/P + m];
-    * ``natural_order=False`` (two all-to-alls): out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2].
+    * ``natural_order=True`` (three exchanges): X[rank*n/P + m];
+    * ``natural_order=False`` (two exchanges): out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2].
 
-    Local passes: one block copy that packs the first exchange, the n1-point FFTs on the
-    strided columns with the inter-step twiddle folded into their last store, the n2-point
-    FFTs reading the second exchange's blocks in place (segmented load), and for natural
-    order one transpose after the third exchange.  With several ranks the first exchange is
-    pipelined in `chunks` row groups like fft2_slab's.
+    Schedule with several ranks (mfft_plan_1d_dist runs the same one inside libmfft.so).  The n2
+    columns j2 are cut into P*G segments of Wc columns; rank q transforms segment g*P + q as its
+    group g.
+
+    * pack + first exchange, group-major: one strided block copy packs group g of the local rows
+      per destination; the first group is packed and sent in `chunks` row chunks;
+    * columns: the n1-point transforms of a group (inter-step twiddle folded into their last store)
+      run while the next group travels; their rows [q*R1, (q+1)*R1) belong to rank q, are
+      contiguous, and leave while the next group is transformed -- into the region the group
+      arrived in, so sample j2 of local row i ends up at [j2 // Wc][i][j2 % Wc];
+    * rows: the last group travels in row chunks, and the n2-point transforms of a chunk's rows read
+      those segments in place while the next chunk is on the links;
+    * natural order: bin k2 of row i goes to [k2 // W2][i][k2 % W2] (the owner of natural index
+      k2*n1 + k1), a chunk leaves for its owners while the next one is transformed, and one
+      transpose ends the transform.
     """
     P = comm.world
     if n1 % P or n2 % P:
@@ -444,82 +515,84 @@ def fft1d_fourstep(x_local, n1, n2, comm: Comm, ops, natural_order=True, chunks=
     if x_local.numel() != R1 * n2:
         raise ValueError("x_local has the wrong size for this rank's chunk")
     if isinstance(comm, CComm):
-        return comm.run("1d", x_local, n1, n2, natural_order, chunks)
+        return comm.run("1d", x_local, n1, n2, natural_order, chunks, col_groups)
     bufs = _Buffers(ops, R1 * n2, x_local)
+    X = bufs.free(x_local)
+    Y = bufs.free(X)
 
-    # pack: local rows j1 (R1 x P x W2) -> [s][i][c]; destination s owns columns [s*W2, (s+1)*W2)
+    def columns(src, dst, wc, c0, scratch):
+        """dst[k1][c] = W_n^(k1 * (c0 + c)) * sum_j1 W_n1^(j1 k1) src[j1][c] on an (n1 x wc) matrix"""
+        if ops.columns_ok(n1, wc, src):
+            ops.fft_columns(src, dst, n=n1, inner=wc, twiddle=(n, c0))
+            return
+        assert wc == W2                            # shapes outside the tile passes: one group, through transposes
+        ops.transpose(src, dst, rows=n1, cols=W2)          # (W2 x n1): each local column contiguous
+        ops.fft(dst, scratch, n=n1, batch=W2)
+        ops.twiddle(scratch, rows=W2, cols=n1, r0=c0, c0=0, n_total=n)
+        ops.transpose(scratch, dst, rows=W2, cols=n1)      # (n1 x W2)
+
     if P == 1:
-        cur = x_local
-    else:
-        x = bufs.free(x_local)
-        C = _chunk_count(chunks, R1, P)
-        if C == 1:
-            ops.swap_axes(x_local, x, a=R1, b=P, w=W2)
-            cur = comm.all_to_all(bufs.free(x), x, "samples->columns")     # cur[r][i][c] = x[(r*R1 + i)*n2 + rank*W2 + c]: (n1 x W2)
-        else:
-            Rc = R1 // C
-            cur = bufs.free(x)
-            pending = []
-            for c in range(C):
-                sb = x[c * Rc * n2:(c + 1) * Rc * n2]      # [s][i][col], P x Rc x W2
-                ops.swap_axes(x_local[c * Rc * n2:(c + 1) * Rc * n2], sb, a=Rc, b=P, w=W2)
-                sends = [sb[s * Rc * W2:(s + 1) * Rc * W2] for s in range(P)]
-                recvs = [cur[(r * R1 + c * Rc) * W2:(r * R1 + (c + 1) * Rc) * W2] for r in range(P)]
-                pending.append(comm.start_exchange(sends, recvs, f"samples->columns[{c}/{C}]"))
-            for h in pending:
-                h.wait()
-    nxt = bufs.free(cur)
-    if ops.columns_ok(n1, W2, cur):
-        # A[k1][c] = W_n^(k1 * (rank*W2 + c)) * sum_j1 W_n1^(j1 k1) cur[j1][c]
-        ops.fft_columns(cur, nxt, n=n1, inner=W2, twiddle=(n, comm.rank * W2))
-        cur = nxt
-    else:
-        ops.transpose(cur, nxt, rows=n1, cols=W2)  # (W2 x n1): each local column contiguous
-        tmp = bufs.free(nxt, x_local)
-        ops.fft(nxt, tmp, n=n1, batch=W2)
-        ops.twiddle(tmp, rows=W2, cols=n1, r0=comm.rank * W2, c0=0, n_total=n)
-        cur = bufs.free(tmp, x_local)
-        ops.transpose(tmp, cur, rows=W2, cols=n1)  # (n1 x W2)
-    seg_in = (W2, W2, R1 * W2)      # sample j2 of local row i sits at [j2 // W2][i][j2 % W2]
-    if P == 1:
-        out = bufs.free(cur, x_local)
-        ops.fft(cur, out, n=n2, batch=R1)
+        columns(x_local, X, W2, 0, Y)
+        ops.fft(X, Y, n=n2, batch=R1)
         if not natural_order:
-            return out
-        res = bufs.free(out, x_local)
-        ops.transpose(out, res, rows=n1, cols=W2)
-        return res
-    # Second exchange + n2-point transforms, chunked over this rank's rows k1: rows k1 in [s*R1, (s+1)*R1)
-    # belong to rank s and are contiguous; the blocks of chunk c (rows [c*Rc, +Rc) from every peer) are
-    # transformed while chunk c + 1 travels.  For natural order bin k2 of row i goes to
-    # [k2 // W2][i][k2 % W2] (the owner of natural index k2*n1 + k1) and chunk c leaves for its owners
-    # -- into the regions of `res` that the transform has just consumed -- while chunk c + 1 is transformed.
-    C2 = _chunk_count(chunks, R1, P)
-    Rc, piece = R1 // C2, (R1 // C2) * W2
-    res = bufs.free(cur, x_local)
-    extra = ops.empty(R1 * n2, x_local)
+            return Y
+        ops.transpose(Y, X, rows=n1, cols=W2)
+        return X
+    G = _group_count(col_groups, W2, P, ops.min_group_cols(x_local))
+    while G > 1 and not ops.columns_ok(n1, W2 // G, x_local):
+        G -= 1
+        while G > 1 and W2 % G:
+            G -= 1
+    C = _chunk_count(chunks, R1, P)
+    Rc, Wc = R1 // C, W2 // G
+    blk, gsz = R1 * Wc, P * R1 * Wc                # one (peer, group) block; one group's (n1 x Wc) column matrix
 
-    def second(c):
-        sends = [cur[(s * R1 + c * Rc) * W2:(s * R1 + c * Rc) * W2 + piece] for s in range(P)]
-        recvs = [res[r * R1 * W2 + c * piece:r * R1 * W2 + (c + 1) * piece] for r in range(P)]
-        return comm.start_exchange(sends, recvs, f"columns->rows[{c}/{C2}]")
+    def unit(src_of, g, c, nck, label):
+        piece = blk // nck
+        sends = [src_of(q)[:piece] for q in range(P)]
+        recvs = [Y[g * gsz + q * blk + c * piece:g * gsz + q * blk + (c + 1) * piece] for q in range(P)]
+        return comm.start_exchange(sends, recvs, label)
 
-    handle, third = second(0), []
-    for c in range(C2):
-        ahead = second(c + 1) if c + 1 < C2 else None
-        handle.wait()
-        if natural_order:
-            ops.fft(res[c * piece:], extra[c * piece:], n=n2, batch=Rc, in_layout=seg_in, out_layout=seg_in)
-            sends = [extra[s * R1 * W2 + c * piece:s * R1 * W2 + (c + 1) * piece] for s in range(P)]
-            recvs = [res[r * R1 * W2 + c * piece:r * R1 * W2 + (c + 1) * piece] for r in range(P)]
-            third.append(comm.start_exchange(sends, recvs, f"natural order[{c}/{C2}]"))
-        else:
-            ops.fft(res[c * piece:], extra[c * Rc * n2:], n=n2, batch=Rc, in_layout=seg_in)
-        handle = ahead
+    arriving = {g: [] for g in range(G)}
+    for g in range(G):
+        nck = C if g == 0 else 1
+        rows, piece = R1 // nck, blk // nck
+        for c in range(nck):
+            pack = X[g * gsz + c * P * piece:g * gsz + (c + 1) * P * piece]     # [q][i][w], P x rows x Wc
+            ops.swap_axes(x_local[c * rows * n2 + g * P * Wc:], pack, a=rows, b=P, w=Wc, strides=(n2, Wc))
+            arriving[g].append(unit(lambda q, pack=pack, piece=piece: pack[q * piece:], g, c, nck,
+                                    f"samples->columns[group {g}/{G}, chunk {c}/{nck}]"))
+    out = ops.empty(R1 * n2, x_local)
+    landing = []
+    for g in range(G):
+        _wait_all(arriving[g])
+        columns(Y[g * gsz:(g + 1) * gsz], X[g * gsz:(g + 1) * gsz], Wc, (g * P + comm.rank) * Wc, out)
+        nck = C if g == G - 1 else 1
+        piece = blk // nck
+        for c in range(nck):
+            landing.append(unit(lambda q, g=g, c=c, piece=piece: X[g * gsz + q * blk + c * piece:], g, c, nck,
+                                f"columns->rows[group {g}/{G}, chunk {c}/{nck}]"))
+    _wait_all(landing[:G - 1])
+    # The natural-order exchange lands in a buffer of its own here: X is still being sent from by the last
+    # group's later chunks, and only a transport that runs its transfers in issue order (one RCCL stream,
+    # as inside libmfft.so) could reuse it.
+    T = ops.empty(R1 * n2, x_local) if natural_order else None
+    seg_in = (Wc, Wc, R1 * Wc)                     # sample j2 of local row i sits at [j2 // Wc][i][j2 % Wc]
+    seg_out = (W2, W2, R1 * W2)
+    run = Rc * W2
+    third = []
+    for c in range(C):
+        landing[G - 1 + c].wait()
+        if not natural_order:
+            ops.fft(Y[c * Rc * Wc:], out[c * Rc * n2:], n=n2, batch=Rc, in_layout=seg_in)
+            continue
+        ops.fft(Y[c * Rc * Wc:], out[c * run:], n=n2, batch=Rc, in_layout=seg_in, out_layout=seg_out)
+        sends = [out[q * R1 * W2 + c * run:q * R1 * W2 + (c + 1) * run] for q in range(P)]
+        recvs = [T[q * R1 * W2 + c * run:q * R1 * W2 + (c + 1) * run] for q in range(P)]
+        third.append(comm.start_exchange(sends, recvs, f"natural order[{c}/{C}]"))
     if not natural_order:
-        return extra                               # out[i*n2 + k2] = X[(rank*R1 + i) + n1*k2]
-    for h in third:
-        h.wait()
-    # res[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: an (n1 x W2) matrix whose transpose is the natural-order chunk
-    ops.transpose(res, cur, rows=n1, cols=W2)
-    return cur
+        return out                                 # out[i*n2 + k2] = X[(rank*R1 + i) + n1*k2]
+    _wait_all(third)
+    # T[r][i][c] = X[(rank*W2 + c)*n1 + r*R1 + i]: an (n1 x W2) matrix whose transpose is the natural-order chunk
+    ops.transpose(T, out, rows=n1, cols=W2)
+    return out

@@ -220,7 +220,9 @@ class ColumnPlan(Plan):
     also multiplies output (k, c) by exp(-2 pi i k (c0 + c) / n_total).  Raises MfftError
     for shapes the tile passes do not serve (callers then transpose and use Plan)."""
 
-    def __init__(self, n: int, inner: int, batch: int = 1, dtype: int = _lib.C64, twiddle=None):
+    def __init__(self, n: int, inner: int, batch: int = 1, dtype: int = _lib.C64, twiddle=None, out_ld=None):
+        """out_ld: elements between consecutive rows of the result (default inner: dense); a plan with
+        out_ld > inner writes a block of columns of a wider array and runs on device buffers only."""
         lib = _lib.load()
         self.n = self.n_in = int(n)
         self.inner = int(inner)
@@ -229,8 +231,10 @@ class ColumnPlan(Plan):
         self.flags = 0
         self._h = ctypes.c_void_p()
         tw_n, tw_c0 = (int(twiddle[0]), int(twiddle[1])) if twiddle is not None else (0, 0)
-        _lib.check(lib.mfft_plan_1d_columns(ctypes.byref(self._h), self.n, self.inner, self.batch,
-                                            self.dtype, tw_n, tw_c0))
+        self.out_ld = int(out_ld) if out_ld else self.inner
+        self._has_layout = self.out_ld != self.inner          # the output extent is the caller's: not checked
+        _lib.check(lib.mfft_plan_1d_columns_ld(ctypes.byref(self._h), self.n, self.inner, self.batch,
+                                               self.dtype, tw_n, tw_c0, self.out_ld))
         self._lock = threading.Lock()
 
     def exec_host(self, x: np.ndarray):

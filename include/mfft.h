@@ -112,6 +112,12 @@ int mfft_plan_1d_layout(mfft_plan* out, int64_t n, int64_t n_in, int64_t batch, 
  * algorithm, folded into the last pass' store. */
 int mfft_plan_1d_columns(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
                          int64_t twiddle_n, int64_t twiddle_c0);
+/* The same with the rows of the RESULT out_ld >= inner elements apart (0 or inner: dense): the transform
+ * of a block of `inner` columns written straight into its place in a wider (n x out_ld) array, as
+ * np.fft.fft(a[:, c0:c0+inner], axis=0) assigned to out[:, c0:c0+inner] -- the column groups of the
+ * 2-D decomposition.  mfft_exec only; n * out_ld <= 2^32; excludes the fused twiddle. */
+int mfft_plan_1d_columns_ld(mfft_plan* out, int64_t n, int64_t inner, int64_t batch, int dtype,
+                            int64_t twiddle_n, int64_t twiddle_c0, int64_t out_ld);
 int mfft_plan_destroy(mfft_plan plan);
 
 /* Bytes of device workspace the plan holds, and the number of kernel launches
@@ -261,6 +267,11 @@ int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, in
  * elements (np.swapaxes(x.reshape(a, b, w), 0, 1) made contiguous). */
 int mfft_swap_axes(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w, int dtype,
                    void* stream);
+/* out[j][i][:] = in[i*in_stride_a + j*in_stride_b + (0..w)], i < a, j < b: the same block copy reading
+ * rows that are not adjacent (in_stride_a = b*w, in_stride_b = w is mfft_swap_axes) -- one column group
+ * of an exchange packed out of, or unpacked into, rows of the full width. */
+int mfft_swap_axes_strided(const void* d_in, void* d_out, int64_t a, int64_t b, int64_t w,
+                           int64_t in_stride_a, int64_t in_stride_b, int dtype, void* stream);
 
 /* x[r][c] *= exp(-2*pi*i * (r0 + r)*(c0 + c) / n_total)  on a rows x cols complex tile
  * (the inter-step twiddle of the four-step algorithm). */
@@ -271,8 +282,8 @@ int mfft_twiddle_tile(void* d_x, int64_t rows, int64_t cols, int64_t r0, int64_t
  * No counterpart in the reference (it never leaves one process): BASELINE configurations 4 and 5,
  * np.fft.fft2 of an n0 x n1 array held in row slabs and np.fft.fft of ONE signal of n1*n2 points
  * held in contiguous chunks, one rank per GPU.  Exchanges are groups of RCCL point-to-point
- * transfers over xGMI, cut into row chunks and overlapped with the transforms that produce or
- * consume them; packing and unpacking happen inside the transform kernels' own loads and stores.
+ * transfers over xGMI, cut into column groups and row chunks and overlapped with the transforms that
+ * produce or consume them; packing and unpacking happen inside the transform kernels' own loads and stores.
  * RCCL (librccl.so.1) is loaded on first use; single-GPU callers never load it.
  *
  * Communicators.  mfft_comm_unique_id: rank 0 makes a 128-byte id and hands it to every rank by
@@ -299,22 +310,31 @@ int mfft_comm_exchange(mfft_comm comm, const void* const* d_send, void* const* d
  *                                        out[k0*(n1/P) + c] = F[k0][rank*(n1/P) + c];
  *   restore_layout != 0 (two exchanges): the input's own layout, out[i*n1 + k1] = F[rank*(n0/P) + i][k1].
  * Both dimensions must divide by the number of ranks; shapes the column-batched passes do not
- * serve return MFFT_E_UNSUPPORTED.  chunks: row chunks per exchange (<= 0: 4; 1 with one rank). */
+ * serve return MFFT_E_UNSUPPORTED.
+ * Schedule.  col_groups (<= 0: 4): this rank's n1/P columns are cut into that many groups (fewer when a group
+ * would be narrower than 64 complex128 / 128 complex64 columns); the groups are exchanged one after the
+ * other, and a group that has arrived is transformed along the strided axis -- and, with restore_layout,
+ * sent back -- while the next one travels.  chunks (<= 0: 4): row chunks of the group at either end of that
+ * pipeline, so that the row transforms overlap the first group's exchange and the unpacking the last
+ * group's.  Both are 1 with one rank; col_groups = 1 is the schedule that chunks by rows only. */
 int mfft_plan_2d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n0, int64_t n1, int dtype,
-                      int restore_layout, int chunks);
+                      int restore_layout, int chunks, int col_groups);
 
 /* Forward DFT of ONE signal of n = n1*n2 points (four-step split) distributed in contiguous
  * chunks.  Input: this rank's n/P consecutive samples.  Output, n/P elements:
  *   natural_order != 0 (three exchanges): X[rank*n/P + m];
- *   natural_order == 0 (two exchanges):   out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2]. */
+ *   natural_order == 0 (two exchanges):   out[i*n2 + k2] = X[(rank*(n1/P) + i) + n1*k2].
+ * chunks, col_groups: as for mfft_plan_2d_dist, over this rank's n2/P columns of the n1 x n2 view: the
+ * first exchange, the n1-point transforms and the second exchange form a pipeline over the column groups,
+ * the n2-point transforms (and the natural-order exchange) one over the row chunks of the last group. */
 int mfft_plan_1d_dist(mfft_dist_plan* out, mfft_comm comm, int64_t n1, int64_t n2, int dtype,
-                      int natural_order, int chunks);
+                      int natural_order, int chunks, int col_groups);
 
 /* Run a distributed plan on device buffers (d_in != d_out; d_in is not modified), kernels on
  * `stream`, exchanges on a stream of the plan ordered against it by events.  Asynchronous;
  * collective: every rank of the communicator calls it with its own plan, in the same order. */
 int mfft_dist_exec(mfft_dist_plan plan, const void* d_in, void* d_out, void* stream);
-int mfft_dist_plan_info(mfft_dist_plan plan, int* chunks, int64_t* workspace_bytes);
+int mfft_dist_plan_info(mfft_dist_plan plan, int* chunks, int* col_groups, int64_t* workspace_bytes);
 int mfft_dist_plan_destroy(mfft_dist_plan plan);
 
 #ifdef __cplusplus

@@ -28,10 +28,14 @@ class NumpyOps:
     def __init__(self, columns=True):
         self.columns = columns
 
-    def columns_ok(self, n, inner, like, batch=1):
+    @staticmethod
+    def min_group_cols(like):
+        return 1                                   # the stand-in has no minimum segment length
+
+    def columns_ok(self, n, inner, like, batch=1, out_ld=None):
         return self.columns
 
-    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None):
+    def fft_columns(self, src, dst, n, inner, batch=1, twiddle=None, out_ld=None):
         assert self.columns
         x = src.numpy()[: batch * n * inner].reshape(batch, n, inner)
         y = np.fft.fft(x, axis=1)
@@ -40,11 +44,19 @@ class NumpyOps:
             k = np.arange(n, dtype=np.int64)[:, None]
             c = (c0 + np.arange(inner, dtype=np.int64))[None, :]
             y = y * np.exp(-2j * np.pi * ((k * c) % n_total) / n_total)[None]
-        dst.numpy()[: batch * n * inner] = y.reshape(-1)
+        if out_ld is None or out_ld == inner:
+            dst.numpy()[: batch * n * inner] = y.reshape(-1)
+        else:                                      # rows of the result out_ld elements apart
+            assert batch == 1
+            d = dst.numpy()
+            rows = np.arange(n, dtype=np.int64)[:, None] * out_ld + np.arange(inner, dtype=np.int64)[None, :]
+            d[rows] = y[0]
 
-    def swap_axes(self, src, dst, a, b, w):
-        x = src.numpy()[: a * b * w].reshape(a, b, w)
-        dst.numpy()[: a * b * w] = x.transpose(1, 0, 2).reshape(-1)
+    def swap_axes(self, src, dst, a, b, w, strides=None):
+        sa, sb = strides if strides is not None else (b * w, w)
+        idx = (np.arange(b, dtype=np.int64)[:, None, None] * sb + np.arange(a, dtype=np.int64)[None, :, None] * sa
+               + np.arange(w, dtype=np.int64)[None, None, :])
+        dst.numpy()[: a * b * w] = src.numpy()[idx].reshape(-1)
 
     def empty(self, count, like):
         import torch
@@ -107,13 +119,14 @@ def worker(rank, world, port, use_gpu, results_dir):
                 F = np.fft.fft2(A)
                 R, W = n0 // world, n1 // world
                 mine = torch.from_numpy(A[rank * R:(rank + 1) * R].reshape(-1).copy()).to(dev)
-                for chunks in (1, 2, 4, None):
-                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False, chunks=chunks)
+                # row chunks x column groups of the pipelined schedule (col_groups 1: chunked by rows only)
+                for chunks, groups in ((1, 1), (2, 1), (4, 1), (None, 1), (1, 2), (2, 2), (2, 3), (None, None), (1, None)):
+                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=False, chunks=chunks, col_groups=groups)
                     out = out.cpu().numpy().reshape(n0, W)
-                    errs[f"fft2_cols_{tag}_{n0}_{chunks}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
-                for chunks in (1, 2, 3, None):                   # the return exchange is chunked as well
-                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True, chunks=chunks)
-                    errs[f"fft2_rows_{tag}_{n0}_{chunks}"] = rel_l2(out.cpu().numpy().reshape(R, n1), F[rank * R:(rank + 1) * R])
+                    errs[f"fft2_cols_{tag}_{n0}_{chunks}_{groups}"] = rel_l2(out, F[:, rank * W:(rank + 1) * W])
+                for chunks, groups in ((1, 1), (2, 1), (3, 1), (None, 1), (1, 2), (2, 2), (2, 3), (None, None), (1, None)):
+                    out = fd.fft2_slab(mine, n0, n1, comm, vops, restore_layout=True, chunks=chunks, col_groups=groups)
+                    errs[f"fft2_rows_{tag}_{n0}_{chunks}_{groups}"] = rel_l2(out.cpu().numpy().reshape(R, n1), F[rank * R:(rank + 1) * R])
                 assert np.array_equal(mine.cpu().numpy(), A[rank * R:(rank + 1) * R].reshape(-1)), "input clobbered"
 
             # ---- 1-D four-step ---------------------------------------------------------
@@ -123,14 +136,15 @@ def worker(rank, world, port, use_gpu, results_dir):
                 X = np.fft.fft(x)
                 chunk = n // world
                 mine = torch.from_numpy(x[rank * chunk:(rank + 1) * chunk].copy()).to(dev)
-                for chunks in (1, 2, 3, None):                   # second and third exchange chunked around the row transforms
-                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True, chunks=chunks).cpu().numpy()
-                    errs[f"fft1d_N_{tag}_{n1f}_{chunks}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
+                combos = ((1, 1), (2, 1), (3, 1), (None, 1), (1, 2), (2, 2), (2, 4), (None, None), (1, None))
+                for chunks, groups in combos:
+                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=True, chunks=chunks, col_groups=groups).cpu().numpy()
+                    errs[f"fft1d_N_{tag}_{n1f}_{chunks}_{groups}"] = rel_l2(out, X[rank * chunk:(rank + 1) * chunk])
                 R1 = n1f // world
                 want = X.reshape(n2f, n1f).T[rank * R1:(rank + 1) * R1]      # [k1][k2] = X[k1 + n1*k2]
-                for chunks in (1, 2, 3, None):
-                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=False, chunks=chunks).cpu().numpy()
-                    errs[f"fft1d_T_{tag}_{n1f}_{chunks}"] = rel_l2(out.reshape(R1, n2f), want)
+                for chunks, groups in combos:
+                    out = fd.fft1d_fourstep(mine, n1f, n2f, comm, vops, natural_order=False, chunks=chunks, col_groups=groups).cpu().numpy()
+                    errs[f"fft1d_T_{tag}_{n1f}_{chunks}_{groups}"] = rel_l2(out.reshape(R1, n2f), want)
                 assert np.array_equal(mine.cpu().numpy(), x[rank * chunk:(rank + 1) * chunk]), "input clobbered"
 
         # ---- batch sharding: no collective ------------------------------------------

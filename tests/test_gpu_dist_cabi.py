@@ -44,7 +44,7 @@ def _run_ranks(comms, fn):
     return out
 
 
-def _check_2d(fd, comms, n0, n1, dtype, chunks):
+def _check_2d(fd, comms, n0, n1, dtype, chunks, groups=None):
     import torch
     P = len(comms)
     cdt = np.complex64 if dtype == 0 else np.complex128
@@ -56,17 +56,17 @@ def _check_2d(fd, comms, n0, n1, dtype, chunks):
             torch.cuda.set_device(0)
             with torch.cuda.stream(torch.cuda.Stream()):
                 loc = torch.from_numpy(a[c.rank * R:(c.rank + 1) * R].reshape(-1)).cuda()
-                res = [fd.fft2_slab(loc, n0, n1, c, None, restore_layout=restore, chunks=chunks) for _ in range(2)]
+                res = [fd.fft2_slab(loc, n0, n1, c, None, restore_layout=restore, chunks=chunks, col_groups=groups) for _ in range(2)]
                 torch.cuda.current_stream().synchronize()
                 assert torch.equal(res[0], res[1])                      # re-execution of the same plan
                 return res[1].cpu().numpy()
         outs = _run_ranks(comms, one)
         for r, o in enumerate(outs):
             want = ref[r * R:(r + 1) * R] if restore else ref[:, r * W:(r + 1) * W]
-            assert rel_l2(o.reshape(want.shape), want) < TOL[dtype], (P, n0, n1, restore, r)
+            assert rel_l2(o.reshape(want.shape), want) < TOL[dtype], (P, n0, n1, restore, r, chunks, groups)
 
 
-def _check_1d(fd, comms, n1, n2, dtype, chunks):
+def _check_1d(fd, comms, n1, n2, dtype, chunks, groups=None):
     import torch
     P = len(comms)
     cdt = np.complex64 if dtype == 0 else np.complex128
@@ -80,7 +80,7 @@ def _check_1d(fd, comms, n1, n2, dtype, chunks):
             with torch.cuda.stream(torch.cuda.Stream()):
                 loc = torch.from_numpy(x[c.rank * cnt:(c.rank + 1) * cnt]).cuda()
                 keep = loc.clone()
-                res = fd.fft1d_fourstep(loc, n1, n2, c, None, natural_order=natural, chunks=chunks)
+                res = fd.fft1d_fourstep(loc, n1, n2, c, None, natural_order=natural, chunks=chunks, col_groups=groups)
                 torch.cuda.current_stream().synchronize()
                 assert torch.equal(loc, keep), "the input must not be modified"
                 return res.cpu().numpy()
@@ -91,7 +91,7 @@ def _check_1d(fd, comms, n1, n2, dtype, chunks):
             else:                                                       # out[i*n2 + k2] = X[(r*R1 + i) + n1*k2]
                 k1 = r * R1 + np.arange(R1)
                 want = ref[k1[:, None] + n1 * np.arange(n2)[None, :]].reshape(-1)
-            assert rel_l2(o, want) < TOL[dtype], (P, n1, n2, natural, r)
+            assert rel_l2(o, want) < TOL[dtype], (P, n1, n2, natural, r, chunks, groups)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -137,6 +137,13 @@ def test_local_ranks_run_the_multi_rank_paths(P, dtype):
             _check_1d(fd, comms, 16 * P if 16 * P >= 64 else 64, wmin * P, dtype, chunks)
         _check_2d(fd, comms, 1024, 1024, dtype, None)
         _check_1d(fd, comms, 1024, 512, dtype, None)
+        # column groups: wide enough for 1, 2, 3 (-> 2) and the default 4 groups of at least 64 / 128 columns
+        wide = (128 if dtype == 0 else 64) * 4 * P
+        for chunks, groups in ((1, 1), (None, 2), (2, 3), (None, None), (1, 4)):
+            _check_2d(fd, comms, 64 * P, wide, dtype, chunks, groups)
+            _check_1d(fd, comms, 256, wide, dtype, chunks, groups)
+        lib_info = comms[0].plan_info(comms[0].plan("1d", 256, wide, dtype, True, None, None))
+        assert lib_info[0] == 4 and lib_info[1] == 4, lib_info
     finally:
         for c in comms:
             c.close()
@@ -150,15 +157,15 @@ def test_dist_plan_argument_errors():
     comms = fd.CComm.local(2)
     try:
         h = ctypes.c_void_p()
-        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 63, 64, 0, 0, 0) == _lib.E_INVALID
-        assert lib.mfft_plan_1d_dist(ctypes.byref(h), comms[0]._h, 64, 63, 0, 0, 0) == _lib.E_INVALID
-        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 64, 7, 0, 0) == _lib.E_INVALID
-        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 16, 0, 0, 0) == _lib.E_UNSUPPORTED   # 8 local columns
-        assert lib.mfft_plan_2d_dist(ctypes.byref(h), None, 64, 64, 0, 0, 0) == _lib.E_INVALID
-        _lib.check(lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 64, 0, 1, 0))
-        ch, ws = ctypes.c_int(), ctypes.c_int64()
-        _lib.check(lib.mfft_dist_plan_info(h, ctypes.byref(ch), ctypes.byref(ws)))
-        assert ch.value == 4 and ws.value == 2 * 32 * 64 * 8
+        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 63, 64, 0, 0, 0, 0) == _lib.E_INVALID
+        assert lib.mfft_plan_1d_dist(ctypes.byref(h), comms[0]._h, 64, 63, 0, 0, 0, 0) == _lib.E_INVALID
+        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 64, 7, 0, 0, 0) == _lib.E_INVALID
+        assert lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 16, 0, 0, 0, 0) == _lib.E_UNSUPPORTED   # 8 local columns
+        assert lib.mfft_plan_2d_dist(ctypes.byref(h), None, 64, 64, 0, 0, 0, 0) == _lib.E_INVALID
+        _lib.check(lib.mfft_plan_2d_dist(ctypes.byref(h), comms[0]._h, 64, 64, 0, 1, 0, 0))
+        ch, gr, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        _lib.check(lib.mfft_dist_plan_info(h, ctypes.byref(ch), ctypes.byref(gr), ctypes.byref(ws)))
+        assert ch.value == 4 and gr.value == 1 and ws.value == 2 * 32 * 64 * 8      # 32 local columns: one group
         d = torch.zeros(32 * 64, dtype=torch.complex64, device="cuda")
         assert lib.mfft_dist_exec(h, d.data_ptr(), d.data_ptr(), None) == _lib.E_INVALID          # in place
         lib.mfft_dist_plan_destroy(h)

@@ -138,6 +138,14 @@ def test_layouts_through_every_route(fa, dtype):
         # n, n_in, batch, flags, in_layout, out_layout
         (1024, 1024, 5, 0, (256, 256, 5 * 256), (128, 128, 5 * 128)),       # fast segmented variant
         (16384 >> dtype, 16384 >> dtype, 3, 0, None, (2048, 2048, 3 * 2048)),
+        # segments shorter than a row of n/16 elements (column groups of the multi-GPU schedules): in, out, both,
+        # at the lengths of the LDS-DMA pipeline and below it
+        (16384 >> dtype, 16384 >> dtype, 5, 0, (128, 128, 5 * 128), None),
+        (16384 >> dtype, 16384 >> dtype, 5, 0, None, (256, 256, 7 * 256)),
+        (8192, 8192, 6, 0, (256 >> dtype, 256 >> dtype, 6 * 256), (128, 128, 9 * 128)),
+        (8192 >> dtype, 8192 >> dtype, 4, 0, (128, 128, 4 * 128), (128, 128, 4 * 128)),
+        (4096, 4096, 7, 0, (128, 128, 7 * 128), (128, 128, 8 * 128)),
+        (2048, 2048, 3, 0, (64 << (1 - dtype), 64 << (1 - dtype), 3 * 128 + 20), (128, 128, 3 * 128)),
         (4096, 4096, 2, 0, (8192, 0, 0), (5000, 0, 0)),                     # strided batches only
         (1024, 1024, 5, fa.HANN, (256, 256, 5 * 256), (32, 32, 5 * 32)),    # window + segments: staged
         (2048, 1500, 3, 0, (500, 500, 3 * 500), (64, 64, 3 * 64)),          # zero padding + segments
@@ -250,3 +258,45 @@ def test_power_with_statistics_full_length(fa, dtype, log2n):
         np.testing.assert_allclose(st[:, 0], ref.max(axis=1), rtol=tol)
         np.testing.assert_allclose(st[:, 1], ref.sum(axis=1), rtol=tol)
         np.testing.assert_allclose(st[:, 2], (ref * f).sum(axis=1), rtol=0, atol=tol * np.abs(ref * f).sum(axis=1).max())
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_strided_block_copy_and_pitched_column_plans(fa, dtype):
+    """mfft_swap_axes_strided (one column group packed out of rows of the full width) against numpy
+    indexing, and mfft_plan_1d_columns_ld (a block of columns transformed straight into its place in a
+    wider array) against np.fft.fft(axis=0) -- the two local pieces of the column-group schedules."""
+    import ctypes
+    import torch
+    from fft_amd import _lib
+    from fft_amd.engine import ColumnPlan
+    lib = _lib.load()
+    cdt = np.complex64 if dtype == 0 else np.complex128
+    tdt = torch.complex64 if dtype == 0 else torch.complex128
+    for a, b, w, sa, sb, off in ((12, 4, 64, 4 * 4 * 64, 64, 2 * 4 * 64), (5, 3, 7, 100, 9, 11), (64, 8, 256, 8192, 256, 4096),
+                                 (1, 1, 1, 1, 1, 0), (33, 2, 16, 32, 16, 0)):
+        total = off + (a - 1) * sa + (b - 1) * sb + w
+        x = _rand(total, a * b + w + dtype, cdt)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((a * b * w + 3,), complex(7.0, -7.0), dtype=tdt, device="cuda")
+        _lib.check(lib.mfft_swap_axes_strided(d_in.data_ptr() + off * x.itemsize, d_out.data_ptr(), a, b, w, sa, sb, dtype, None))
+        torch.cuda.synchronize()
+        idx = off + np.arange(b)[:, None, None] * sb + np.arange(a)[None, :, None] * sa + np.arange(w)[None, None, :]
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:a * b * w], x[idx].reshape(-1)) and np.all(got[a * b * w:] == complex(7.0, -7.0))
+    wmin = 32 if dtype == 0 else 16
+    for n, inner, ld, c0 in ((256, wmin, 4 * wmin, wmin), (4096, 2 * wmin, 8 * wmin, 0), (16384 >> dtype, 64, 256, 128),
+                             (1 << 16, 32, 96, 64), (64, wmin, wmin, 0)):
+        x = _rand((n, inner), n + inner + dtype, cdt)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((n * ld,), complex(7.0, -7.0), dtype=tdt, device="cuda")
+        with ColumnPlan(n, inner, dtype=dtype, out_ld=ld) as p:
+            p.exec(d_in, d_out[c0:])
+            torch.cuda.synchronize()
+        got = d_out.cpu().numpy().reshape(n, ld)
+        assert rel_l2(got[:, c0:c0 + inner], np.fft.fft(x.astype(np.complex128), axis=0)) < TOL[dtype], (n, inner, ld)
+        rest = np.ones((n, ld), bool)
+        rest[:, c0:c0 + inner] = False
+        assert np.all(got[rest] == complex(7.0, -7.0)), "stored outside the column block"
+    h = ctypes.c_void_p()
+    assert lib.mfft_plan_1d_columns_ld(ctypes.byref(h), 256, 64, 1, dtype, 0, 0, 32) == _lib.E_INVALID       # ld below the width
+    assert lib.mfft_plan_1d_columns_ld(ctypes.byref(h), 256, 64, 1, dtype, 1 << 20, 0, 128) == _lib.E_UNSUPPORTED   # with the twiddle

@@ -174,9 +174,9 @@ int main()
                 mfft_dist_plan p2 = nullptr, p1 = nullptr;
                 int rc = hipMalloc(&d_in, (size_t)local * 8) == hipSuccess && hipMalloc(&d_out, (size_t)local * 8) == hipSuccess ? 0 : -99;
                 if (!rc) rc = hipMemcpy(d_in, mine.data(), (size_t)local * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -98;
-                if (!rc) rc = mfft_plan_2d_dist(&p2, comms[r], n0, n1, MFFT_C64, 1, 0);
+                if (!rc) rc = mfft_plan_2d_dist(&p2, comms[r], n0, n1, MFFT_C64, 1, 0, 0);
                 if (!rc) rc = mfft_dist_exec(p2, d_in, d_out, nullptr);
-                if (!rc) rc = mfft_plan_1d_dist(&p1, comms[r], n0, n1, MFFT_C64, 1, 2);
+                if (!rc) rc = mfft_plan_1d_dist(&p1, comms[r], n0, n1, MFFT_C64, 1, 2, 0);
                 if (!rc) rc = mfft_dist_exec(p1, d_in, d_out, nullptr);       // result overwritten below: exercised for its host side
                 if (!rc) rc = mfft_dist_exec(p2, d_in, d_out, nullptr);
                 if (!rc) rc = hipDeviceSynchronize() == hipSuccess ? 0 : -97;
@@ -192,7 +192,7 @@ int main()
         REQUIRE(mfft_comm_info(comms[2], &world, &rank) == MFFT_OK && world == P && rank == 2);
         for (int r = 0; r < P; ++r) REQUIRE(mfft_comm_destroy(comms[r]) == MFFT_OK);
         mfft_dist_plan bad = nullptr;
-        REQUIRE(mfft_plan_2d_dist(&bad, nullptr, 64, 64, MFFT_C64, 0, 0) == MFFT_E_INVALID);
+        REQUIRE(mfft_plan_2d_dist(&bad, nullptr, 64, 64, MFFT_C64, 0, 0, 0) == MFFT_E_INVALID);
     }
     // ---- error paths ---------------------------------------------------------------------------------------
     {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the C ABI's distributed plans over local communicators (2, 4 or 8 ranks sharing the one
 GPU: the multi-rank index algebra, chunked pipelines and event ordering of csrc/dist.hip with device copies as the
-transport): random power-of-two shapes, chunk counts and precisions, both output layouts / orders, against numpy's
+transport): random power-of-two shapes, chunk and column-group counts and precisions, both output layouts / orders, against numpy's
 transform of the assembled input (tests/test_gpu_dist_cabi.py's checkers).  Shapes the tile passes do not serve are
 refused by the library (MfftError) and counted apart.
     python tools/fuzz_dist_local.py [FIRST_SEED [LAST_SEED [CASES_PER_SEED]]]"""
@@ -30,20 +30,21 @@ def run(first, last, cases, verbose=True):
             dtype = int(rng.integers(0, 2))
             wmin = 5 if dtype == 0 else 4
             chunks = [None, 1, 2, 3, 4, 8][int(rng.integers(0, 6))]
+            groups = [None, 1, 2, 3, 4, 8][int(rng.integers(0, 6))]
             comms = fd.CComm.local(P)
             try:
                 if rng.random() < 0.5:
-                    lw = int(rng.integers(wmin, 9))                       # columns per rank
+                    lw = int(rng.integers(wmin, 11))                      # columns per rank
                     n1 = P << lw
                     n0 = 1 << int(rng.integers(max(4, P.bit_length() - 1), 12))
                     while n0 * n1 > (1 << 21):
                         n0 >>= 1
                     if n0 < 16 or n0 % P:
                         continue
-                    case = ("2d", seed, P, n0, n1, dtype, chunks)
-                    chk._check_2d(fd, comms, n0, n1, dtype, chunks)
+                    case = ("2d", seed, P, n0, n1, dtype, chunks, groups)
+                    chk._check_2d(fd, comms, n0, n1, dtype, chunks, groups)
                 else:
-                    lw = int(rng.integers(wmin, 10))
+                    lw = int(rng.integers(wmin, 11))
                     n2 = P << lw
                     if n2 > (8192 if dtype else 16384):
                         continue
@@ -52,8 +53,8 @@ def run(first, last, cases, verbose=True):
                         n1 >>= 1
                     if n1 < 16 or n1 % P:
                         continue
-                    case = ("1d", seed, P, n1, n2, dtype, chunks)
-                    chk._check_1d(fd, comms, n1, n2, dtype, chunks)
+                    case = ("1d", seed, P, n1, n2, dtype, chunks, groups)
+                    chk._check_1d(fd, comms, n1, n2, dtype, chunks, groups)
                 count += 1
             except AssertionError as e:
                 msg = str(e)
