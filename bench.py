@@ -406,7 +406,9 @@ def dist_configs(args, world, rank, c_abi=False):
     out = {"world_size": P, "backend": comm.backend, "transport": "RCCL" if comm.backend == "nccl" else comm.backend,
            "route": "C ABI (mfft_plan_2d_dist / mfft_plan_1d_dist, RCCL send/recv groups)" if c_abi
                     else "fft_amd.dist over torch.distributed",
-           "chunks_first_exchange": fd._chunk_count(None, 1 << 20, P)}
+           "row_chunks": fd._chunk_count(None, 1 << 20, P), "col_groups": fd._group_count(None, 1 << 20, P, 1),
+           "schedule": "column groups exchanged, transformed and sent on while the next group travels; the first and the "
+                       "last group in row chunks"}
     one_gpu = {}
     rpath = os.path.join(ROOT, "profiles", "one_gpu_reference.json")
     if os.path.exists(rpath):

@@ -163,13 +163,16 @@ static int chunk_count(int requested, int64_t rows, int world)
     return (int)(c < 1 ? 1 : c);
 }
 
-// Column groups: the largest divisor of this rank's `cols` columns not above the request (default 4) that
-// leaves groups of at least 64 (complex128) / 128 (complex64) columns -- the shortest segments the
-// contiguous-axis kernels read and write in place, and at least a 1 KiB run per row of a group.
+// Column groups: the largest divisor of this rank's `cols` columns not above the request that leaves groups
+// of at least 64 (complex128) / 128 (complex64) columns -- the shortest segments the contiguous-axis kernels
+// read and write in place, and at least a 1 KiB run per row of a group.  Default 2: the step behind the last
+// exchange (row transforms, unpacking) hides only behind the LAST group's exchange, so more groups shorten
+// the window it has (replayed with measured kernel times and 153 GB/s links at eight ranks: 2^31 complex128
+// 11.2 ms with one group, 7.6 with two, 8.1 with four; 16384^2 complex64 0.47 / 0.39 / 0.44 ms).
 static int group_count(int requested, int64_t cols, int world, int dtype)
 {
     if (world == 1) return 1;
-    int64_t g = requested > 0 ? requested : 4;
+    int64_t g = requested > 0 ? requested : 2;
     const int64_t floor_w = dtype == MFFT_C64 ? 128 : 64;
     if (g > cols) g = cols;
     while (g > 1 && (cols % g || cols / g < floor_w)) --g;

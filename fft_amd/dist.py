@@ -343,13 +343,14 @@ class _Buffers:
 
 def _group_count(requested, cols, world, floor):
     """Column groups of the pipelined schedules: the largest divisor of this rank's `cols` columns not
-    above the request (default 4, MFFT_DIST_GROUPS overrides) that leaves groups of at least `floor`
-    columns; 1 for one rank."""
+    above the request (default 2, MFFT_DIST_GROUPS overrides) that leaves groups of at least `floor`
+    columns; 1 for one rank.  (The step behind the last exchange hides only behind the last group's
+    exchange, so more groups shorten the window it has: tools/local_work_bench.py.)"""
     import os
     if world == 1:
         return 1
     if requested is None:
-        requested = int(os.environ.get("MFFT_DIST_GROUPS", "4"))
+        requested = int(os.environ.get("MFFT_DIST_GROUPS", "2"))
     g = max(1, min(int(requested), cols))
     while g > 1 and (cols % g or cols // g < floor):
         g -= 1

@@ -311,7 +311,7 @@ int mfft_comm_exchange(mfft_comm comm, const void* const* d_send, void* const* d
  *   restore_layout != 0 (two exchanges): the input's own layout, out[i*n1 + k1] = F[rank*(n0/P) + i][k1].
  * Both dimensions must divide by the number of ranks; shapes the column-batched passes do not
  * serve return MFFT_E_UNSUPPORTED.
- * Schedule.  col_groups (<= 0: 4): this rank's n1/P columns are cut into that many groups (fewer when a group
+ * Schedule.  col_groups (<= 0: 2): this rank's n1/P columns are cut into that many groups (fewer when a group
  * would be narrower than 64 complex128 / 128 complex64 columns); the groups are exchanged one after the
  * other, and a group that has arrived is transformed along the strided axis -- and, with restore_layout,
  * sent back -- while the next one travels.  chunks (<= 0: 4): row chunks of the group at either end of that

@@ -137,13 +137,13 @@ def test_local_ranks_run_the_multi_rank_paths(P, dtype):
             _check_1d(fd, comms, 16 * P if 16 * P >= 64 else 64, wmin * P, dtype, chunks)
         _check_2d(fd, comms, 1024, 1024, dtype, None)
         _check_1d(fd, comms, 1024, 512, dtype, None)
-        # column groups: wide enough for 1, 2, 3 (-> 2) and the default 4 groups of at least 64 / 128 columns
+        # column groups: wide enough for 1, 2 (the default), 3 (-> 2) and 4 groups of at least 64 / 128 columns
         wide = (128 if dtype == 0 else 64) * 4 * P
         for chunks, groups in ((1, 1), (None, 2), (2, 3), (None, None), (1, 4)):
             _check_2d(fd, comms, 64 * P, wide, dtype, chunks, groups)
             _check_1d(fd, comms, 256, wide, dtype, chunks, groups)
         lib_info = comms[0].plan_info(comms[0].plan("1d", 256, wide, dtype, True, None, None))
-        assert lib_info[0] == 4 and lib_info[1] == 4, lib_info
+        assert lib_info[0] == 4 and lib_info[1] == 2, lib_info
     finally:
         for c in comms:
             c.close()
