@@ -116,7 +116,17 @@ def launch_ranks(gpus, argv, port=0):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on these hosts
     env.setdefault("OMP_NUM_THREADS", "1")
     sys.stdout.flush()
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' stdout is relayed: JSON lines to stdout, anything else a library prints there (gloo's
+    # connection notes, RCCL debug output) to stderr, so that stdout carries the one line and nothing else
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    for raw in proc.stdout:
+        text = raw.decode("utf-8", "replace")
+        if text.lstrip().startswith("{"):
+            sys.stdout.write(text)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(text)
+    return proc.wait()
 
 
 def rendezvous_only(args):
