@@ -134,11 +134,13 @@ int launch_wave_c128(int log2n, bool win, bool power, bool real_in, const WaveAr
 // Arguments of the global-pass (tile) kernels, see tile_kernel.h
 // ---------------------------------------------------------------------------
 template <typename T> struct TArgs;
-enum { kTileMinLog2G = 4, kTileMaxLog2G = 9, kTileMaxLog2GNarrow = 12 };   // 10..12: four-column tiles (complex128: 10 only)
+enum { kTileMinLog2G = 4, kTileMaxLog2G = 9, kTileMaxLog2GNarrow = 12 };   // 10..12: four-column tiles (complex128: 1024 x 8 and 2048 x 4)
 int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s);
 int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s);
-int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class
+int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class (TArgs::narrow bits)
 int tile_log2c_c128(int log2g, int narrow);
+bool tile_geometry_c64(int log2g, LdsGeometry* g);    // radices and table shape of a tile's column transforms
+bool tile_geometry_c128(int log2g, LdsGeometry* g);
 bool tile_first_hann_c128(int log2g);         // is there a first pass that evaluates the Hann window (TM_FIRST_HANN) at this radix?
 
 }  // namespace mfft

@@ -195,7 +195,7 @@ struct Pow2Engine {
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
-    int narrow = 0;                     // tile width class (TileCols)
+    int narrow = 0;                     // tile width bits (TArgs::narrow)
     bool table_window = false;          // MFFT_TABLE_WINDOW at build: windowed first passes read the window table (tuning aid)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
@@ -225,7 +225,7 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
         int sum = 0;
         for (const char* p = env; *p;) {
             const int v = (int)strtol(p, const_cast<char**>(&p), 10);
-            if (v < kTileMinLog2G || v > (!log2_inner ? (dtype == MFFT_C64 ? kTileMaxLog2GNarrow : 10) : kTileMaxLog2G)) break;
+            if (v < kTileMinLog2G || v > (!log2_inner ? (dtype == MFFT_C64 ? kTileMaxLog2GNarrow : 11) : kTileMaxLog2G)) break;
             out->push_back(v);
             sum += v;
             if (*p == ',') ++p;
@@ -251,6 +251,24 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
     if (!log2_inner && log2n == 20 && batch == 1 && !getenv("MFFT_NO_NARROW_RADIX")) {
         out->push_back(10);
         out->push_back(10);
+        return MFFT_OK;
+    }
+    // complex128 signals of 2^28 .. 2^31 points: three passes through the 1024 x 8 tiles (128-byte rows, 4.4-4.9
+    // TB/s per pass against 5.0-5.3 for the 256-byte rows of the 512 x 16 ones) instead of four through narrower
+    // radices -- 2^28 6.82 -> 5.21 ms as 1024 * 512 * 512, 2^29 13.6 -> 10.9 as 1024 * 1024 * 512, 2^30 27.7 -> 24.2
+    // as 1024^3; 2^31 needs one 2048 x 4 pass (64-byte rows: 2.7-2.9 TB/s), last, where it costs least:
+    // 54.4 -> 52.8 ms (2048 first: 58.1).  Alternated with the four-pass splits in one process.
+    if (!log2_inner && dtype == MFFT_C128 && log2n >= 28 && log2n <= 31 && !getenv("MFFT_FOUR_PASSES")) {
+        const int third = log2n - 20;                     // 8 .. 11
+        if (third <= 10) {                                // (10, 9, 9), (10, 10, 9), (10, 10, 10)
+            out->push_back(10);
+            out->push_back(third >= 9 ? 10 : 9);
+            out->push_back(third >= 10 ? 10 : 9);
+        } else {
+            out->push_back(10);
+            out->push_back(10);
+            out->push_back(11);
+        }
         return MFFT_OK;
     }
     const int maxg = kTileMaxLog2G;
@@ -315,6 +333,10 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         rc0 = choose_split(log2n, dtype, &split, log2_inner, 1, batch);
     }
     if (rc0) return rc0;
+    // complex128 1024-point tiles: four columns while the plan's data stays in the Infinity Cache (there the 64-byte
+    // rows cost nothing and twice as many tiles fill the CUs: 2^19 x 8 plain 61 against 70 us, 2^20 x 1 Hann + power
+    // 32.4 against 35.1), eight columns -- a full line per row -- beyond it
+    if (dtype == MFFT_C128 && inner == 1 && (size_t)n * (size_t)batch * 16 <= (size_t(384) << 20)) narrow |= 2;
     const int npass = (int)split.size();
     int64_t ns = inner;                 // counts elements: the columns are an innermost, finished "pass"
     for (int s = 0; s < npass; ++s) {
@@ -322,7 +344,7 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
         gp.log2g = split[(size_t)s];
         gp.ns = ns;
         LdsGeometry g{};
-        if (!lds_geometry(dtype, gp.log2g, &g)) { set_error("no geometry for tile radix"); return MFFT_E_UNSUPPORTED; }
+        if (!(dtype == MFFT_C64 ? tile_geometry_c64(gp.log2g, &g) : tile_geometry_c128(gp.log2g, &g))) { set_error("no geometry for tile radix"); return MFFT_E_UNSUPPORTED; }
         build_lds_twiddles(g, &re, &im);
         int rc = upload_complex_dt(dtype, re, im, &gp.d_tw);
         if (rc) { passes.push_back(gp); return rc; }
@@ -362,7 +384,9 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     // every size: its 256-byte rows, written 8 MiB apart, merge in L2 -- 2^27 points 2.68 -> 2.49 ms, the
     // 2^18 x 1024 column step of an eight-rank 2^31-point transform 3.80 -> 3.42 ms, 2^18 x 8192 unchanged
     // (alternated inside one process; 256-point last passes measured equal or worse and keep streaming).
-    if (dtype == MFFT_C128 && !passes.empty() && passes.size() <= 4 && passes.back().log2g == 9 && wbytes > (size_t(384) << 20))
+    // The 1024-point tiles likewise (128-byte rows 16 MiB apart): 2^30 points as 1024^3 26.7 -> 24.2 ms, 2^28 as
+    // 512 * 512 * 1024 6.4 -> 5.3 ms.
+    if (dtype == MFFT_C128 && !passes.empty() && passes.size() <= 4 && passes.back().log2g >= 9 && wbytes > (size_t(384) << 20))
         tile_nt_pass[passes.size() - 1] = 1;
     if (const char* env = getenv("MFFT_TILE_NT")) {                            // tuning aid
         tile_nt = atoi(env) & 3;
@@ -525,8 +549,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.batch = nb;
         a.lb = gp.lb;
         a.nt = (p < 4 && tile_nt_pass[p] >= 0) ? tile_nt_pass[p] : tile_nt;
-        a.xcd = gp.log2g > kTileMaxLog2G ? 1 : 0;       // four-column tiles: neighbours share cache lines,
-        if (a.xcd) a.nt = 0;                             // which streaming accesses would not keep in L2
+        a.xcd = tile_log2c(dtype, gp.log2g, narrow) <= 2 ? 1 : 0;   // four-column tiles: neighbours share cache lines,
+        if (a.xcd) a.nt = 0;                                         // which streaming accesses would not keep in L2
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
@@ -539,13 +563,12 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             a.out_seg = io.out_seg; a.out_seg_stride = io.out_seg_stride;
         }
         const bool in_plain = !io.win && !io.pre && !io.real_in && !io.conj_in && io.n_in == n && io.in_seg == 0;
-        const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 &&
-                               io.scale == (T)1 && !io.power;
+        const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 && !io.power;
         // dense complex samples under the Hann window and / or zero-padded into prefetching tiles: window evaluated
         bool in_hann = false;
         if constexpr (sizeof(T) == 8)
             in_hann = (io.win || io.n_in < n) && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
-                      inner == 1 && !narrow && tile_first_hann_c128(gp.log2g) && !table_window;
+                      inner == 1 && !(narrow & 1) && tile_first_hann_c128(gp.log2g) && !table_window;
         int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : TM_FIRST_GEN))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
         if (inner > 1) {

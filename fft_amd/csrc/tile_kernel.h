@@ -207,9 +207,15 @@ enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN 
 // 128-byte line, which only pays when they run on the same XCD (TArgs::xcd): measured as bare copies
 // of the 4096 x 4 shape, 2.3 TB/s in dispatch order against 5.5 TB/s (strided in, contiguous out)
 // and 1.9 against 4.7 TB/s (strided in and out) with each XCD walking one contiguous tile range.
+// complex128 also has 1024 x 8 tiles (a full 128-byte line per row, the same LDS footprint as 512 x 16) and
+// 2048 x 4 (64-byte rows): with them lengths of 2^28 .. 2^31 points take three passes instead of four.
+#ifndef MFFT_C128_1024_COLS
+#define MFFT_C128_1024_COLS 3     // log2 of the columns of a complex128 1024-point tile (2: the four-column form, for A/B builds)
+#endif
 template <typename T, int LOG2G, bool NARROW> struct TileCols {
-    static constexpr int WIDE = LOG2G >= 10 ? 2 : (sizeof(T) == 4 ? (LOG2G <= 7 ? 6 : (LOG2G == 8 ? 5 : 4)) : (LOG2G <= 8 ? 5 : 4));
-    static constexpr int SLIM = LOG2G >= 10 ? 2 : ((sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0));
+    static constexpr int BIG = (sizeof(T) == 8 && LOG2G == 10) ? MFFT_C128_1024_COLS : 2;
+    static constexpr int WIDE = LOG2G >= 10 ? BIG : (sizeof(T) == 4 ? (LOG2G <= 7 ? 6 : (LOG2G == 8 ? 5 : 4)) : (LOG2G <= 8 ? 5 : 4));
+    static constexpr int SLIM = LOG2G >= 10 ? BIG : ((sizeof(T) == 4 ? 5 : 4) - (LOG2G >= 9 ? 1 : 0));
     static constexpr int LOG2C = NARROW ? SLIM : WIDE;
 };
 
@@ -219,10 +225,15 @@ template <typename T, int LOG2G, bool NARROW> struct TileCols {
 template <int C> constexpr int tile_pitch() { return C >= 8 ? C + 1 : C; }
 template <int G> constexpr int tile_colpitch() { return lds_pad<kPadShift>(G - 1) + 1 + 8; }   // = 8 mod 32 elements
 
-template <int LOG2G> struct TileCfg {
-    using SC = SizeCfg<LOG2G>;
+// Points per thread and radices of a tile's G-point column transforms: those of the LDS-resident kernel of
+// that length, except that the complex128 1024-point tiles run 4 * 16 * 16 with six-generator tables (408
+// entries, 6.4 KiB: with the fifteen-power tables of 16 * 4 * 16 the 1024 x 8 image would not fit LDS).
+template <typename T, int LOG2G> struct TileRadices { using RD = typename SizeCfg<LOG2G>::RD; };
+template <> struct TileRadices<double, 10> { using RD = Radices<4, 16, 16, 1, true>; };
+template <typename T, int LOG2G> struct TileCfg {
+    using RD = typename TileRadices<T, LOG2G>::RD;
     static constexpr int G = 1 << LOG2G;
-    static constexpr int P = SC::P;
+    static constexpr int P = SizeCfg<LOG2G>::P;
     static constexpr int TX = G / P;
 };
 
@@ -275,13 +286,13 @@ template <typename T, int BLOCK, int MODE> constexpr int tile_min_waves()
 }
 
 template <typename T, int LOG2G, int LOG2C, int MODE>
-__global__ void __launch_bounds__(((TileCfg<LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<LOG2G>::TX) << LOG2C), MODE>()))
+__global__ void __launch_bounds__(((TileCfg<T, LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<T, LOG2G>::TX) << LOG2C), MODE>()))
 fft_tile_kernel(const TArgs<T> a)
 {
     constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN || MODE == TM_FIRST_HANN);
     using C_ = cx<T>;
-    using TC = TileCfg<LOG2G>;
-    using RD = typename TC::SC::RD;
+    using TC = TileCfg<T, LOG2G>;
+    using RD = typename TC::RD;
     constexpr int G = TC::G, P = TC::P, TX = TC::TX;
     constexpr int C = 1 << LOG2C;
     constexpr int BLOCK = TX * C;
@@ -612,6 +623,10 @@ fft_tile_kernel(const TArgs<T> a)
             // last pass: NS*G = N, so j < NS and bin k = j + q*NS.  Column-batched plans may store rows of
             // the (n x W) result out_pitch elements apart (a column block of a wider array): row k of the
             // result is (j >> log2_w) + q * (NS >> log2_w), its column j & (W - 1); out_pitch = W is dense
+            if (a.scale != (T)1) {                  // np.fft.fft's norm factors, dt * F: not a reason for the general epilogue
+#pragma unroll
+                for (int e = 0; e < P; ++e) { v[e].x *= a.scale; v[e].y *= a.scale; }
+            }
             const int64_t nso = (a.NS >> a.log2_w) * a.out_pitch;
             C_* __restrict__ out_base = reinterpret_cast<C_*>(a.out) + b * a.out_stride + (j0 >> a.log2_w) * a.out_pitch +
                                         (j0 & ((int64_t(1) << a.log2_w) - 1));
@@ -714,7 +729,7 @@ fft_tile_kernel(const TArgs<T> a)
 template <typename T, int LOG2G, int LOG2C> constexpr size_t tile_lds_bytes()
 {
     constexpr int G = 1 << LOG2G, C = 1 << LOG2C;
-    using RD = typename TileCfg<LOG2G>::SC::RD;
+    using RD = typename TileCfg<T, LOG2G>::RD;
     constexpr size_t image = tile_pitch<C>() == C ? (size_t)tile_colpitch<G>() * C
                                                   : (size_t)(lds_pad<kPadShift>(G - 1) + 1) * tile_pitch<C>();
     return (image + (size_t)tw_total_elems<RD>()) * sizeof(cx<T>);
@@ -723,7 +738,7 @@ template <typename T, int LOG2G, int LOG2C> constexpr size_t tile_lds_bytes()
 template <typename T, int LOG2G, int LOG2C, int MODE>
 int launch_tile_one(const TArgs<T>& a, hipStream_t s)
 {
-    constexpr int BLOCK = TileCfg<LOG2G>::TX << LOG2C;
+    constexpr int BLOCK = TileCfg<T, LOG2G>::TX << LOG2C;
     constexpr size_t lds = tile_lds_bytes<T, LOG2G, LOG2C>();
     static_assert(BLOCK <= 1024, "tile workgroup too large");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
@@ -751,21 +766,10 @@ template <typename T, int LOG2G> constexpr bool tile_first_hann()
     return MFFT_TILE_PF_HANN != 0 && MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && LOG2G == 9;
 }
 
-template <typename T, int LOG2G>
-int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
+// every mode of one radix at one tile width
+template <typename T, int LOG2G, int LC>
+int launch_tile_modes_at(int mode, const TArgs<T>& a, hipStream_t s)
 {
-    constexpr int LC = TileCols<T, LOG2G, false>::LOG2C;
-    constexpr int LN = TileCols<T, LOG2G, true>::LOG2C;
-    if (a.narrow && LN != LC) {
-        // only the modes a column-batched transform uses exist at the narrow width
-        switch (mode) {
-        case TM_MID: return launch_tile_one<T, LOG2G, LN, TM_MID>(a, s);
-        case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LN, TM_LAST_PLAIN>(a, s);
-        case TM_LAST_TWID: return launch_tile_one<T, LOG2G, LN, TM_LAST_TWID>(a, s);
-        }
-        set_error("tile mode not built at the narrow width");
-        return MFFT_E_UNSUPPORTED;
-    }
     switch (mode) {
     case TM_MID: return launch_tile_one<T, LOG2G, LC, TM_MID>(a, s);
     case TM_FIRST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_PLAIN>(a, s);
@@ -780,7 +784,7 @@ int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
             TArgs<T> h = a;
             const int64_t m = a.n_in - 1;
             h.win_inv_m = (double)(1.0L / (long double)m);
-            h.win_step = (double)((long double)(((int64_t)TileCfg<LOG2G>::TX * a.L) % m) / (long double)m);
+            h.win_step = (double)((long double)(((int64_t)TileCfg<T, LOG2G>::TX * a.L) % m) / (long double)m);
             return launch_tile_one<T, LOG2G, LC, TM_FIRST_HANN>(h, s);
         } else {
             break;
@@ -788,6 +792,29 @@ int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
     }
     set_error("unknown tile mode");
     return MFFT_E_INVALID;
+}
+
+// TArgs::narrow: bit 0 = the narrow width class of a column-batched array with few columns (TileCols), bit 1 =
+// the four-column form of the complex128 1024-point tiles (plans whose data stays in the Infinity Cache)
+template <typename T, int LOG2G>
+int launch_tile_mode(int mode, const TArgs<T>& a, hipStream_t s)
+{
+    constexpr int LC = TileCols<T, LOG2G, false>::LOG2C;
+    constexpr int LN = TileCols<T, LOG2G, true>::LOG2C;
+    if ((a.narrow & 1) && LN != LC) {
+        // only the modes a column-batched transform uses exist at the narrow width
+        switch (mode) {
+        case TM_MID: return launch_tile_one<T, LOG2G, LN, TM_MID>(a, s);
+        case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LN, TM_LAST_PLAIN>(a, s);
+        case TM_LAST_TWID: return launch_tile_one<T, LOG2G, LN, TM_LAST_TWID>(a, s);
+        }
+        set_error("tile mode not built at the narrow width");
+        return MFFT_E_UNSUPPORTED;
+    }
+    if constexpr (sizeof(T) == 8 && LOG2G == 10 && LC != 2) {
+        if (a.narrow & 2) return launch_tile_modes_at<T, LOG2G, 2>(mode, a, s);
+    }
+    return launch_tile_modes_at<T, LOG2G, LC>(mode, a, s);
 }
 
 template <typename T>
@@ -801,17 +828,18 @@ int launch_tile_any(int log2g, int mode, const TArgs<T>& a, hipStream_t s)
     case 8: return launch_tile_mode<T, 8>(mode, a, s);
     case 9: return launch_tile_mode<T, 9>(mode, a, s);
     case 10: return launch_tile_mode<T, 10>(mode, a, s);
-#if MFFT_BIG_RADIX      // 2048 and 4096: measured slower than three passes everywhere; kept for the measurement
-    case 11: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 11>(mode, a, s); else break;
+    case 11: if constexpr (sizeof(T) == 8 || MFFT_BIG_RADIX != 0) return launch_tile_mode<T, 11>(mode, a, s); else break;
+#if MFFT_BIG_RADIX      // complex64 2048 and 4096: measured slower than three passes everywhere; kept for the measurement
     case 12: if constexpr (sizeof(T) == 4) return launch_tile_mode<T, 12>(mode, a, s); else break;
 #endif
     }
-    set_error("tile radix outside 16..1024 (complex64 tuning builds: ..4096)");
+    set_error("tile radix outside 16..1024 (complex128: ..2048; complex64 tuning builds: ..4096)");
     return MFFT_E_UNSUPPORTED;
 }
 
-template <typename T> int tile_log2c_for(int log2g, bool narrow)
+template <typename T> int tile_log2c_for(int log2g, int narrow_bits)
 {
+    const bool narrow = (narrow_bits & 1) != 0;
     switch (log2g) {
     case 4: return narrow ? TileCols<T, 4, true>::LOG2C : TileCols<T, 4, false>::LOG2C;
     case 5: return narrow ? TileCols<T, 5, true>::LOG2C : TileCols<T, 5, false>::LOG2C;
@@ -819,9 +847,33 @@ template <typename T> int tile_log2c_for(int log2g, bool narrow)
     case 7: return narrow ? TileCols<T, 7, true>::LOG2C : TileCols<T, 7, false>::LOG2C;
     case 8: return narrow ? TileCols<T, 8, true>::LOG2C : TileCols<T, 8, false>::LOG2C;
     case 9: return narrow ? TileCols<T, 9, true>::LOG2C : TileCols<T, 9, false>::LOG2C;
-    case 10: case 11: case 12: return 2;
+    case 10: return (sizeof(T) == 8 && (narrow_bits & 2)) ? 2 : TileCols<T, 10, false>::LOG2C;
+    case 11: case 12: return 2;
     }
     return 0;
+}
+
+// the radices / table shape of a tile's column transforms, for the host code that builds their twiddle tables
+template <typename T, int LOG2G> void tile_geometry_fill(LdsGeometry* g)
+{
+    using RD = typename TileCfg<T, LOG2G>::RD;
+    *g = LdsGeometry{};
+    g->n = 1 << LOG2G;
+    g->p = TileCfg<T, LOG2G>::P;
+    g->tx = TileCfg<T, LOG2G>::TX;
+    g->npass = RD::npass;
+    for (int i = 0; i < 4; ++i) g->radix[i] = RD::r[i];
+    g->split16 = RD::split16 ? 1 : 0;
+    g->tw_elems = (size_t)tw_total_elems<RD>();
+}
+template <typename T> bool tile_geometry_for(int log2g, LdsGeometry* g)
+{
+    switch (log2g) {
+#define MFFT_TG(L) case L: tile_geometry_fill<T, L>(g); return true;
+        MFFT_TG(4) MFFT_TG(5) MFFT_TG(6) MFFT_TG(7) MFFT_TG(8) MFFT_TG(9) MFFT_TG(10) MFFT_TG(11) MFFT_TG(12)
+#undef MFFT_TG
+    }
+    return false;
 }
 
 }  // namespace mfft

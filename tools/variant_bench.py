@@ -24,6 +24,8 @@ def load(tag):
     name = "libmfft.so" if tag == "default" else f"libmfft_{tag}.so"
     lib = ctypes.CDLL(os.path.join(ROOT, "fft_amd", "lib", name))
     for fn, (res, args) in L.SIGNATURES.items():
+        if not hasattr(lib, fn):          # an older build of the library: entry points added since are absent
+            continue
         getattr(lib, fn).restype = res
         getattr(lib, fn).argtypes = args
     return lib
