@@ -12,10 +12,10 @@ from . import _lib
 from .engine import Plan, ColumnPlan
 from ._lib import C64, C128, HANN, POWER, DEMOD, REAL_IN, STATS, INVERSE, MfftError, device_count
 from .npfft import fft, fft2, fftfreq, clear_plan_cache
-from .spectral import (fft_from_timeseries, fft_from_timeseries_batch, fft_extract_E_p, power_spectrum, return_amplitude,
+from .spectral import (fft_from_timeseries, fft_from_timeseries_batch, fft_from_timeseries_blocks, fft_extract_E_p, power_spectrum, return_amplitude,
                        return_amplitude_block_general, Heff_block_general)
 
 __all__ = ["Plan", "ColumnPlan", "C64", "C128", "HANN", "POWER", "DEMOD", "REAL_IN", "STATS", "INVERSE",
            "MfftError", "device_count", "fft", "fft2", "fftfreq", "clear_plan_cache",
-           "fft_from_timeseries", "fft_from_timeseries_batch", "fft_extract_E_p", "power_spectrum", "return_amplitude",
+           "fft_from_timeseries", "fft_from_timeseries_batch", "fft_from_timeseries_blocks", "fft_extract_E_p", "power_spectrum", "return_amplitude",
            "return_amplitude_block_general", "Heff_block_general"]

@@ -1557,12 +1557,24 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
 
 static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, double t0, double dt,
-                    const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
-                    int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram)
+// The samples of a line search: handed over by the caller (h_x), or generated on the device from the
+// eigen-data of `nblocks` small Hermitian blocks (the batch's return amplitudes f(t), final2.py:85-97).
+struct LineSource {
+    const void* h_x = nullptr;
+    const AmpArgs* blocks = nullptr;      // one per signal of the batch
+};
+
+static int lines_run(mfft_plan plan, const LineSource& src, double scale, double mu, double t0, double dt,
+                     const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
+                     int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram)
 {
-    if (!plan || !h_x || !prm || !h_idx || !h_omega_hat || !h_count || !h_stats) { set_error("null argument"); return MFFT_E_INVALID; }
+    const void* h_x = src.h_x;
+    if (!plan || (!h_x && !src.blocks) || !prm || !h_idx || !h_omega_hat || !h_count || !h_stats) { set_error("null argument"); return MFFT_E_INVALID; }
     Plan* p = reinterpret_cast<Plan*>(plan);
+    if (src.blocks) {
+        if (!h_times) { set_error("the amplitude generator needs the time grid"); return MFFT_E_INVALID; }
+        if (p->dtype != MFFT_C128 || (p->flags & MFFT_REAL_IN)) { set_error("the amplitude generator writes complex128 samples"); return MFFT_E_UNSUPPORTED; }
+    }
     const uint32_t need = MFFT_POWER | MFFT_STATS;
     if ((p->flags & need) != need || p->kind == Plan::COLUMNS) { set_error("the line search needs an MFFT_POWER | MFFT_STATS plan"); return MFFT_E_INVALID; }
     if (p->lin.batch_stride || p->lin.seg || p->lout.batch_stride || p->lout.seg) { set_error("host entry points serve dense layouts only"); return MFFT_E_UNSUPPORTED; }
@@ -1634,15 +1646,26 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     double* d_E = reinterpret_cast<double*>(d + o_E);
     const double* d_t = reinterpret_cast<const double*>(d + o_t);
 
-    memcpy(h_up + o_x, h_x, in_bytes);
-    if (h_gram) memcpy(h_up + o_t, h_times, sizeof(double) * (size_t)n_in);
+    if (h_x) memcpy(h_up + o_x, h_x, in_bytes);
+    if (h_gram || src.blocks) memcpy(h_up + o_t, h_times, sizeof(double) * (size_t)n_in);
     // no return may leave this stream (or the side stream below) working on the plan's buffers, or writing
     // into its pinned ones, behind the caller's back
     struct StreamSync {
         hipStream_t s; bool armed;
         ~StreamSync() { if (armed) (void)hipStreamSynchronize(s); }
     } main_sync{sm, true};
-    MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, sm));
+    if (src.blocks) {
+        // only the time grid goes up; every block's f(t) is written where the transform reads it
+        MFFT_HIP(hipMemcpyAsync(d + o_t, h_up + o_t, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, sm));
+        int64_t gblocks = (n_in + 255) / 256;
+        if (gblocks > 4096) gblocks = 4096;
+        for (int64_t b = 0; b < B; ++b)
+            hipLaunchKernelGGL(return_amplitude_kernel, dim3((unsigned)gblocks), dim3(256), 0, sm,
+                               reinterpret_cast<cx<double>*>(d + o_x) + b * n_in, n_in, d_t, 0.0, 0.0, src.blocks[b]);
+        MFFT_HIP(hipGetLastError());
+    } else {
+        MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, sm));
+    }
     int rc = plan_exec_ordered(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, sm);
     if (rc) return rc;
     // The spectra leave on a stream of their own as soon as the transform is done -- normalised into a
@@ -1750,6 +1773,33 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
     if (h_gram) memcpy(h_gram, h_down + (o_gram - o_down), sizeof(double) * (size_t)B * nres);
     if (pooled) CopyPool::out().wait(ticket);
     return MFFT_OK;
+}
+
+int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, double t0, double dt,
+                    const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
+                    int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram)
+{
+    if (!h_x) { set_error("null argument"); return MFFT_E_INVALID; }
+    LineSource src;
+    src.h_x = h_x;
+    return lines_run(plan, src, scale, mu, t0, dt, h_times, prm, normalize, h_S, h_stats, h_idx, h_omega_hat, h_height, h_count, h_gram);
+}
+
+int mfft_lines_blocks_host(mfft_plan plan, const double* h_w, const double* h_c0, const double* h_vrow, int nk, double hbar,
+                           double scale, const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S,
+                           double* h_stats, int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count,
+                           double* h_gram)
+{
+    if (!plan || !h_w || !h_c0 || !h_vrow) { set_error("null argument"); return MFFT_E_INVALID; }
+    const int64_t B = reinterpret_cast<Plan*>(plan)->batch;
+    std::vector<AmpArgs> blocks((size_t)B);
+    for (int64_t b = 0; b < B; ++b) {
+        const int rc = amp_args(&blocks[(size_t)b], h_w + b * nk, h_c0 + 2 * b * nk, h_vrow + 2 * b * nk, nk, hbar);
+        if (rc) return rc;
+    }
+    LineSource src;
+    src.blocks = blocks.data();
+    return lines_run(plan, src, scale, 0.0, 0.0, 1.0, h_times, prm, normalize, h_S, h_stats, h_idx, h_omega_hat, h_height, h_count, h_gram);
 }
 
 int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const double* d_max, int dtype,

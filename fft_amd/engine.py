@@ -195,6 +195,40 @@ class Plan:
                 hgt.ctypes.data, cnt.ctypes.data, gram.ctypes.data if gram is not None else None))
         return {"S": S, "stats": stats, "idx": idx, "omega_hat": om, "height": hgt, "count": cnt, "gram": gram}
 
+    def exec_host_lines_blocks(self, w, c0, vrow, times, *, hbar: float = 1.0, axis_dt: float, guard: float, want: int,
+                               dc_guard: float = 0.0, include_dc: bool = False, mode: int = 0, scale: float = 1.0,
+                               want_spectrum: bool = True, want_fit: bool = True, normalize: bool = False):
+        """exec_host_lines with the samples generated on the device (mfft_lines_blocks_host): signal b is the
+        return amplitude sum_k vrow[b, k] exp(-i w[b, k] t / hbar) c0[b, k] on the grid `times`.  w: (batch, nk)
+        float64; c0, vrow: (batch, nk) complex128.  Returns the same dict."""
+        if self._h is None:
+            raise ValueError("plan already destroyed")
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        c0 = np.ascontiguousarray(c0, dtype=np.complex128)
+        vrow = np.ascontiguousarray(vrow, dtype=np.complex128)
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        B = self.batch
+        if w.ndim != 2 or w.shape[0] != B or c0.shape != w.shape or vrow.shape != w.shape:
+            raise ValueError(f"block data must be (batch, nk) arrays for a batch of {B}")
+        if t.shape[0] != self.n_in:
+            raise ValueError("`times` must have one entry per sample")
+        want = int(want)
+        prm = _lib.PeakParams(float(axis_dt), float(dc_guard), float(guard), int(bool(include_dc)), int(mode), want)
+        S = np.empty((B, self.n), dtype=self.out_dtype) if want_spectrum else None
+        stats = np.zeros((B, 3), dtype=np.float64)
+        idx = np.empty((B, max(want, 1)), dtype=np.int64)
+        om = np.empty((B, max(want, 1)), dtype=np.float64)
+        hgt = np.empty((B, max(want, 1)), dtype=np.float64)
+        cnt = np.zeros(B, dtype=np.int32)
+        gram = np.empty((B, 2 * want * want + 2 * want + 1), dtype=np.float64) if want_fit else None
+        with self._lock:
+            _lib.check(_lib.load().mfft_lines_blocks_host(
+                self._h, w.ctypes.data, c0.ctypes.data, vrow.ctypes.data, int(w.shape[1]), float(hbar), float(scale),
+                t.ctypes.data, ctypes.byref(prm), int(bool(normalize)),
+                S.ctypes.data if S is not None else None, stats.ctypes.data, idx.ctypes.data, om.ctypes.data,
+                hgt.ctypes.data, cnt.ctypes.data, gram.ctypes.data if gram is not None else None))
+        return {"S": S, "stats": stats, "idx": idx, "omega_hat": om, "height": hgt, "count": cnt, "gram": gram}
+
     # -- lifetime ---------------------------------------------------------------
     def destroy(self):
         if getattr(self, "_h", None) is not None and self._h.value:

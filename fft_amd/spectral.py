@@ -258,6 +258,13 @@ def fft_from_timeseries_batch(
     res = plan.exec_host_lines(x, times, axis_dt=dt, guard=guard_mult * domega, want=want,
                                dc_guard=dc_guard * domega, include_dc=bool(include_dc), mode=0, scale=dt,
                                want_spectrum=True, want_fit=True, normalize=True)
+    return _tuples_from_lines(res, nfft, dt, want, post_prune, min_weight, keep_top)
+
+
+def _tuples_from_lines(res, nfft, dt, want, post_prune, min_weight, keep_top):
+    """The host tail of estimator A for every signal of a device pass: weights from the normal equations,
+    pruning, sorting (final2.py:176-188) -> [(E_hat ascending, p, -omega, S_norm)]."""
+    B = len(res["count"])
     E_axis = -_omega_axis(nfft, dt)                # one fresh array per call, shared by the batch's tuples
     counts = [int(c) for c in res["count"]]
     weights = _batch_weights(res["gram"], counts, want) if B > 1 else None
@@ -315,6 +322,71 @@ def fft_from_timeseries(
     return fft_from_timeseries_batch([f_t], times, n_levels=n_levels, pad_factor=pad_factor, use_hann=use_hann,
                                      include_dc=include_dc, dc_guard=dc_guard, post_prune=post_prune,
                                      min_weight=min_weight, keep_top=keep_top, guard_mult=guard_mult)[0]
+
+
+def fft_from_timeseries_blocks(
+    K,
+    J,
+    m_list,
+    site,
+    times,
+    n_levels=3,
+    pad_factor=16,
+    use_hann=True,
+    include_dc=False,
+    dc_guard=1.5,
+    post_prune=True,
+    min_weight=1e-6,
+    keep_top=None,
+    guard_mult=1.2,
+    hbar=1.0,
+):
+    """The app's loop over blocks (final2.py:752-758, :853-859)
+
+        for m in m_list:
+            f_t = return_amplitude_block_general(K, J, m, site=site, times=times)
+            ... = fft_from_timeseries(f_t, times, ...)
+
+    as ONE device pass that never brings f(t) to the host: the L x L blocks are diagonalised here
+    (L <= 10), each block's return amplitude is generated on the device straight into the batched
+    transform's input (final2.py:85-97), and the spectra, the peak pipeline and the normal equations
+    follow as in `fft_from_timeseries_batch`.  Only the time grid goes up.  Returns one
+    ``(E_hat ascending, p, -omega, S_norm)`` per entry of ``m_list``, each what
+    ``fft_from_timeseries(return_amplitude_block_general(K, J, m, site, times), times, ...)`` returns."""
+    times = np.asarray(times, float)
+    if times.ndim != 1 or times.size < 2:
+        raise ValueError("`times` must be 1D with length >= 2.")
+    steps = np.diff(times)
+    if not np.allclose(steps, steps[0]):
+        raise ValueError("`times` must be uniformly spaced.")
+    dt = float(steps[0])
+    m_list = list(m_list)
+    if not m_list:
+        return []
+    L = len(np.asarray(K, float))
+    if L > 32:
+        raise ValueError("blocks larger than 32 x 32 are not supported by the device generator")
+    B = len(m_list)
+    w = np.empty((B, L))
+    c0 = np.empty((B, L), complex)
+    vrow = np.empty((B, L), complex)
+    for b, m in enumerate(m_list):
+        ev, V = np.linalg.eigh(Heff_block_general(K, J, m))      # final2.py:81-83
+        w[b] = ev.real
+        c0[b] = V.conj().T[:, site]                              # V^H |site>
+        vrow[b] = V[site, :]
+    n0 = times.shape[0]
+    nfft = int(max(1, pad_factor) * n0)
+    want = max(n_levels, 1)
+    if want > 64:
+        raise ValueError("at most 64 spectral lines can be fitted at once")
+    domega = TWO_PI / (times[-1] - times[0] + 1e-12)
+    flags = _lib.POWER | _lib.STATS | (_lib.HANN if use_hann else 0)
+    plan = cached_plan(nfft, n0, B, _lib.C128, flags)
+    res = plan.exec_host_lines_blocks(w, c0, vrow, times, hbar=hbar, axis_dt=dt, guard=guard_mult * domega, want=want,
+                                      dc_guard=dc_guard * domega, include_dc=bool(include_dc), mode=0, scale=dt,
+                                      want_spectrum=True, want_fit=True, normalize=True)
+    return _tuples_from_lines(res, nfft, dt, want, post_prune, min_weight, keep_top)
 
 
 # --------------------------------------------------------------------------- estimator B

@@ -198,6 +198,19 @@ int mfft_lines_host(mfft_plan plan, const void* h_x, double scale, double mu, do
                     const double* h_times, const mfft_peak_params* prm, int normalize, void* h_S, double* h_stats,
                     int64_t* h_idx, double* h_omega_hat, double* h_height, int32_t* h_count, double* h_gram);
 
+/* The same with the samples GENERATED on the device instead of uploaded: signal b of the batch is the return
+ * amplitude f_b(t_j) of a small Hermitian block (formula and arguments as mfft_return_amplitude_host below;
+ * h_w batch*nk eigenvalues, h_c0 / h_vrow batch*nk complex, the same nk <= 32 for every block), written
+ * straight into the transform's input.  This is the body of the loop over blocks m,
+ *     f_t = return_amplitude_block_general(K, J, m, site, times); fft_from_timeseries(f_t, times, ...)
+ * (final2.py:752-758, :830-835, :853-859), as one call in which only the time grid goes up and the results
+ * come down.  plan: complex128, MFFT_POWER | MFFT_STATS, no MFFT_REAL_IN / MFFT_DEMOD; h_times: the n_in
+ * sample times (always needed).  Everything else as mfft_lines_host. */
+int mfft_lines_blocks_host(mfft_plan plan, const double* h_w, const double* h_c0, const double* h_vrow, int nk,
+                           double hbar, double scale, const double* h_times, const mfft_peak_params* prm,
+                           int normalize, void* h_S, double* h_stats, int64_t* h_idx, double* h_omega_hat,
+                           double* h_height, int32_t* h_count, double* h_gram);
+
 /* ---- weights of the spectral lines ----------------------------------------------
  * Normal equations of the windowed least-squares fit both estimators end with
  * (final2.py:174-175: lstsq(exp(-1j*outer(times, E)) * win[:, None], f_t*win);

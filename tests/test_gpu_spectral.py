@@ -185,6 +185,43 @@ def test_return_amplitude_generator(fa, golden):
     np.testing.assert_allclose(p, z["p_1"], atol=1e-9)
 
 
+def test_resident_block_pipeline_equals_the_loop_over_blocks(fa, golden):
+    """fft_from_timeseries_blocks -- f(t) of every block generated on the device straight into the batched
+    transform's input -- against the goldens of the reference's own loop (final2.py:752-758 at the sidebar
+    defaults, blocks m = 0, 1, 2) and against the oracle, to the tolerances of the single-signal test."""
+    z = golden("final2_defaults.npz")
+    times = np.arange(0.0, float(z["tmax"]) + float(z["dt"]), float(z["dt"]))
+    kw = dict(n_levels=3, pad_factor=32, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=3)
+    out = fa.fft_from_timeseries_blocks(z["K"], z["J"], [0, 1, 2], 0, times, **kw)
+    assert len(out) == 3
+    for m, (E, p, Eaxis, S_norm) in zip((0, 1, 2), out):
+        np.testing.assert_allclose(E, z[f"E_{m}"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(p, z[f"p_{m}"], rtol=0, atol=1e-9)
+        assert int(np.argmax(S_norm)) == int(z[f"argmax_{m}"]) and S_norm.max() == 1.0
+        assert rel_l2(S_norm[::61], z[f"Snorm_sub_{m}"]) < 1e-12
+        assert np.array_equal(Eaxis[::61], z[f"Eaxis_sub_{m}"])
+        Eo, po, _, Sn_o = so.fft_from_timeseries(so.return_amplitude_block(z["K"], z["J"], m, 0, times), times, **kw)
+        np.testing.assert_allclose(E, Eo, atol=1e-9)
+        np.testing.assert_allclose(p, po, atol=1e-9)
+        assert rel_l2(S_norm, Sn_o) < 1e-12
+    # any order / subset of blocks, another site, the function's own defaults, hbar != 1; and the empty list
+    K, J = [1.0, 0.7, 1.3, 0.4], [0.5, 1.5, 0.9]
+    t2 = np.arange(3000) * 0.02
+    for ms, site, kw2 in (([3, 1], 2, {}), ([2], 0, dict(use_hann=False, pad_factor=4, post_prune=False)),
+                          ([0, 1, 2, 3], 1, dict(hbar=0.7, n_levels=4, keep_top=4))):
+        got = fa.fft_from_timeseries_blocks(K, J, ms, site, t2, **kw2)
+        kw_ref = {k: v for k, v in kw2.items() if k != "hbar"}
+        for m, (E, p, Eaxis, S_norm) in zip(ms, got):
+            f = so.return_amplitude_block(K, J, m, site, t2 / kw2.get("hbar", 1.0))
+            Eo, po, Eax_o, Sn_o = so.fft_from_timeseries(f, t2, **kw_ref)
+            np.testing.assert_allclose(E, Eo, atol=1e-8)
+            np.testing.assert_allclose(p, po, atol=1e-7)
+            assert rel_l2(S_norm, Sn_o) < 1e-11 and np.array_equal(Eaxis, Eax_o)
+    assert fa.fft_from_timeseries_blocks(K, J, [], 0, t2) == []
+    with pytest.raises(ValueError):
+        fa.fft_from_timeseries_blocks(K, J, [0], 0, np.array([0.0, 1.0, 3.0]))
+
+
 def test_local_maxima_scan(fa):
     """Device-side candidate scan (final2.py:151, streamlit_app_combined.py:218) against the
     numpy expression, bit-exact on indices, including plateaus, ties, tiny arrays and overflow."""
