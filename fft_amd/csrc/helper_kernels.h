@@ -180,6 +180,39 @@ __global__ void seg_copy_kernel(const E* src, E* dst, int64_t batch, int64_t cou
     }
 }
 
+// Spectrum of a real signal of n = 2M samples from the M-point transform Z of its packed form
+// z[j] = x[2j] + i x[2j+1]:
+//     X[k] = (Z[k] + conj Z[M-k]) / 2  -  i w^k (Z[k] - conj Z[M-k]) / 2,   w = exp(-2 pi i / n),  0 <= k <= M
+//     X[n-k] = conj X[k]                                                      0 <  k <  M
+// (indices of Z modulo M).  One thread per k: Z is read once forwards and once backwards, every bin of the
+// full spectrum is written once -- as scale * X, or as |scale * X|^2 when POWER.  The root w^k is evaluated
+// (exact integer reduction, tile_root) in double for both precisions.
+template <typename T, bool POWER>
+__global__ void __launch_bounds__(256) r2c_split_kernel(const cx<T>* Z, void* out, int64_t M, int log2n, int64_t z_stride,
+                                                        int64_t out_stride, T scale)
+{
+    const int64_t b = blockIdx.y;
+    const cx<T>* z = Z + b * z_stride;
+    const int64_t n = 2 * M;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= M; k += (int64_t)gridDim.x * blockDim.x) {
+        const cx<T> A = z[k & (M - 1)], B = z[(M - k) & (M - 1)];
+        const cx<double> w = tile_root((uint64_t)k, log2n);
+        const double er = 0.5 * ((double)A.x + (double)B.x), ei = 0.5 * ((double)A.y - (double)B.y);
+        const double orr = 0.5 * ((double)A.y + (double)B.y), oi = -0.5 * ((double)A.x - (double)B.x);
+        const double xr = (er + (w.x * orr - w.y * oi)) * (double)scale, xi = (ei + (w.x * oi + w.y * orr)) * (double)scale;
+        if constexpr (POWER) {
+            T* o = static_cast<T*>(out) + b * out_stride;
+            const T sp = (T)(xr * xr + xi * xi);
+            o[k] = sp;
+            if (k > 0 && k < M) o[n - k] = sp;
+        } else {
+            cx<T>* o = static_cast<cx<T>*>(out) + b * out_stride;
+            o[k] = cx<T>{(T)xr, (T)xi};
+            if (k > 0 && k < M) o[n - k] = cx<T>{(T)xr, (T)(-xi)};
+        }
+    }
+}
+
 // out[b][a][:] = in[a*sa + b*sb + (0..W)] for complex elements (sa = B*W, sb = W: an (A, B, W) array with
 // its two leading axes swapped): one row of W contiguous elements per loop trip, copied 16 bytes per
 // lane where W and the strides allow

@@ -141,6 +141,7 @@ template <typename T> struct Io {
     double* stats = nullptr;
     int64_t n_in = 0, n_out = 0;
     int real_in = 0, conj_in = 0, conj_out = 0;
+    int win_pairs = 0;     // `win` weighs the real and the imaginary part of every sample separately (packed real input)
     T scale = 1;
     bool power = false;
     int64_t batch = 0;     // > 0: transform only this many signals (a slab of the plan's batch)
@@ -208,6 +209,7 @@ struct Pow2Engine {
     // (and so overwrites all of them) whenever the transform takes several passes
     bool stats_by_reduction(bool power, int64_t out_seg) const { return !single && power && out_seg == 0 && work[0] != nullptr; }
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
+    template <typename T> int reduce_stats(const T* S, int64_t n_out, int64_t stride, int64_t nb, double* stats, hipStream_t s);
 };
 
 static int tile_log2c(int dtype, int log2g, int narrow)
@@ -425,6 +427,7 @@ void Pow2Engine::release()
 template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
 {
     const int64_t nb = io.batch > 0 ? io.batch : batch;
+    if (single && io.win_pairs) { set_error("pair windows exist in the tile passes only"); return MFFT_E_UNSUPPORTED; }
     if (single) {
         KArgs<T> a{};
         a.in = io.in; a.out = io.out;
@@ -554,6 +557,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
+            a.win_pairs = io.win_pairs;
             a.real_in = io.real_in; a.conj_in = io.conj_in;
             a.in_seg = io.in_seg; a.in_seg_stride = io.in_seg_stride;
         }
@@ -567,7 +571,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         // dense complex samples under the Hann window and / or zero-padded into prefetching tiles: window evaluated
         bool in_hann = false;
         if constexpr (sizeof(T) == 8)
-            in_hann = (io.win || io.n_in < n) && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
+            in_hann = (io.win || io.n_in < n) && !io.win_pairs && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
                       inner == 1 && !(narrow & 1) && tile_first_hann_c128(gp.log2g) && !table_window;
         int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : TM_FIRST_GEN))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
@@ -588,17 +592,21 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         src = a.out;
         src_stride = nn;
     }
-    if (stats_after) {
-        // the workspace is dead once the last pass has read it: it holds the per-block partials
-        int64_t nblk = (io.n_out + 4095) / 4096;
-        if (nblk > 256) nblk = 256;
-        if ((size_t)nb * (size_t)nblk * 3 * sizeof(double) > work_bytes || nb > 65535) { set_error("statistics scratch too small"); return MFFT_E_UNSUPPORTED; }
-        double* partial = static_cast<double*>(work[0]);
-        hipLaunchKernelGGL(stats_partial_kernel<T>, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, s,
-                           static_cast<const T*>(io.out), io.n_out, io.out_stride, partial);
-        hipLaunchKernelGGL(stats_final_kernel, dim3((unsigned)nb), dim3(64), 0, s, (const double*)partial, (int)nblk, io.stats);
-        MFFT_HIP(hipGetLastError());
-    }
+    if (stats_after) return reduce_stats<T>(static_cast<const T*>(io.out), io.n_out, io.out_stride, nb, io.stats, s);
+    return MFFT_OK;
+}
+
+// {max, sum, centroid} of `nb` finished power spectra by a two-stage reduction; the pass workspace, dead once
+// the last pass has read it, holds the per-block partials
+template <typename T> int Pow2Engine::reduce_stats(const T* S, int64_t n_out, int64_t stride, int64_t nb, double* stats, hipStream_t s)
+{
+    int64_t nblk = (n_out + 4095) / 4096;
+    if (nblk > 256) nblk = 256;
+    if (!work[0] || (size_t)nb * (size_t)nblk * 3 * sizeof(double) > work_bytes || nb > 65535) { set_error("statistics scratch too small"); return MFFT_E_UNSUPPORTED; }
+    double* partial = static_cast<double*>(work[0]);
+    hipLaunchKernelGGL(stats_partial_kernel<T>, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, s, S, n_out, stride, partial);
+    hipLaunchKernelGGL(stats_final_kernel, dim3((unsigned)nb), dim3(64), 0, s, (const double*)partial, (int)nblk, stats);
+    MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }
 
@@ -621,6 +629,8 @@ struct Plan {
     void* d_chirp = nullptr; // exp(-i pi j^2 / n), j < n            (CHIRPZ)
     void* d_filt = nullptr;  // conj(FFT_m(conj chirp, wrapped)), m   (CHIRPZ)
     void* d_conv = nullptr;  // batch * m complex workspace            (CHIRPZ)
+    bool packed_real = false;// POW2 + MFFT_REAL_IN above one LDS residency: the engine transforms n/2 packed samples
+    void* d_half = nullptr;  // batch * n/2 complex: that transform's result, split into the n bins by r2c_split_kernel
     // staging for mfft_exec_host
     void* d_in = nullptr;
     void* d_out = nullptr;
@@ -678,7 +688,7 @@ static void plan_free(Plan* p)
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     (void)hipSetDevice(p->device);
     p->eng.release();
-    for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_in, p->d_out, (void*)p->d_stats,
+    for (void* q : {p->d_win, p->d_pre, p->d_chirp, p->d_filt, p->d_conv, p->d_half, p->d_in, p->d_out, (void*)p->d_stats,
                     (void*)p->d_peaks, (void*)p->d_lines})
         if (q) (void)hipFree(q);
     if (p->s_spec) (void)hipStreamDestroy(p->s_spec);
@@ -810,6 +820,25 @@ static int plan_build_parts(Plan* p)
     }
     if (is_pow2(p->n)) {
         p->kind = Plan::POW2;
+        // Real input whose HALF-length transform still takes several passes: packed form.  z[j] = x[2j] + i x[2j+1]
+        // is the input buffer itself read as complex, every pass moves half the bytes of the complex route, and one
+        // streaming kernel splits the n/2 bins into the n of the real signal's spectrum.  (Shorter real signals are
+        // read as reals by the single-kernel variants: one pass either way.)
+        // Measured against the promoting route (alternated in one process, 2^24 points per launch): complex128
+        // 0.78-0.89 of its time from 2^15 points on; complex64 0.79-0.86 from 2^20 on, but 0.97-1.12 below (there
+        // the split kernel's extra launch and pass outweigh the halved two-pass transform).
+        const int from = p->dtype == MFFT_C64 ? 20 : 15;
+        if ((p->flags & MFFT_REAL_IN) && !(p->flags & (MFFT_DEMOD | MFFT_INVERSE)) && ilog2(p->n) >= from && (p->n_in & 1) == 0 &&
+            !p->lin.batch_stride && !p->lin.seg && !p->lout.batch_stride && !p->lout.seg && !getenv("MFFT_NO_R2C")) {
+            p->packed_real = true;
+            rc = p->eng.build(p->n / 2, p->batch, p->dtype);
+            if (rc) return rc;
+            const size_t half_bytes = (size_t)p->batch * (size_t)(p->n / 2) * 2 * real_size(p->dtype);
+            MFFT_HIP(hipMalloc(&p->d_half, half_bytes));
+            p->workspace += p->eng.bytes + (int64_t)half_bytes;
+            p->launches = p->eng.launches() + 1 + ((p->flags & MFFT_STATS) ? 2 : 0);
+            return MFFT_OK;
+        }
         rc = p->eng.build(p->n, p->batch, p->dtype);
         if (rc) return rc;
         if (p->flags & MFFT_DEMOD) {
@@ -846,7 +875,7 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
     double* stats = (p->flags & MFFT_STATS) ? d_stats : nullptr;
     // kernels that accumulate the statistics with atomics need them cleared; the multi-pass engine
     // (chirp-z and long transforms) writes all three values from a reduction of its own
-    if (stats && !p->eng.stats_by_reduction(power, p->lout.seg))
+    if (stats && !p->packed_real && !p->eng.stats_by_reduction(power, p->lout.seg))
         MFFT_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 3 * (size_t)nb, s));
     if (demod && tables) {
         const int rc = launch_premul<T>(p, mu, t0, dt, 1, s);
@@ -874,6 +903,30 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
         io.n_in = io.n_out = p->n;
         io.batch = slab;
         return p->eng.exec<T>(io, s);
+    }
+    if (p->kind == Plan::POW2 && p->packed_real) {
+        const int64_t M = p->n / 2;
+        Io<T> io;                                       // the input read as n_in/2 complex samples
+        io.in = d_in; io.out = p->d_half;
+        io.in_stride = p->n_in / 2; io.out_stride = M;
+        io.win = win; io.win_pairs = win ? 1 : 0;       // the n_in real weights, taken two at a time
+        io.n_in = p->n_in / 2; io.n_out = M;
+        io.batch = slab;
+        int rc = p->eng.exec<T>(io, s);
+        if (rc) return rc;
+        int64_t blocks = (M + 1 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (nb > 65535) { set_error("at most 65535 real signals per call above one LDS residency"); return MFFT_E_UNSUPPORTED; }
+        const dim3 grid((unsigned)blocks, (unsigned)nb);
+        if (power)
+            hipLaunchKernelGGL((r2c_split_kernel<T, true>), grid, dim3(256), 0, s, static_cast<const cx<T>*>(p->d_half), d_out, M,
+                               ilog2(p->n), M, p->n, (T)scale);
+        else
+            hipLaunchKernelGGL((r2c_split_kernel<T, false>), grid, dim3(256), 0, s, static_cast<const cx<T>*>(p->d_half), d_out, M,
+                               ilog2(p->n), M, p->n, (T)scale);
+        MFFT_HIP(hipGetLastError());
+        if (stats) return p->eng.reduce_stats<T>(static_cast<const T*>(d_out), p->n, p->n, nb, stats, s);
+        return MFFT_OK;
     }
     if (p->kind == Plan::POW2) {
         Io<T> io;

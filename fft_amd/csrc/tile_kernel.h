@@ -116,7 +116,8 @@ template <typename T> struct TArgs {
     int log2_ns;          // NS = 1 << log2_ns
     int log2_tiles;       // tiles per signal = (L / C) = 1 << log2_tiles
     int real_in, conj_in, conj_out;
-    int narrow;           // 1: the narrow tile width (see TileCols)
+    int win_pairs;        // FIRST: `win` holds one weight for the real and one for the imaginary part of every sample
+    int narrow;           // tile width bits (see launch_tile_mode)
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
     T scale;
@@ -453,8 +454,15 @@ fft_tile_kernel(const TArgs<T> a)
                 for (int e = 0; e < P; ++e) v[e].y = -v[e].y;
             }
             if (a.win) {
+                if (a.win_pairs) {
+                    // packed real samples z[j] = x[2j] + i x[2j+1]: each part takes its own weight
+                    const C_* __restrict__ wp = reinterpret_cast<const C_*>(a.win);
 #pragma unroll
-                for (int e = 0; e < P; ++e) { const T wv = a.win[idx[e]]; v[e].x *= wv; v[e].y *= wv; }
+                    for (int e = 0; e < P; ++e) { const C_ w2 = wp[idx[e]]; v[e].x *= w2.x; v[e].y *= w2.y; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) { const T wv = a.win[idx[e]]; v[e].x *= wv; v[e].y *= wv; }
+                }
             }
             if (a.pre) {
 #pragma unroll

@@ -439,3 +439,51 @@ def test_column_plans_on_random_shapes(fa):
     del fz.failures[:]
     assert fz.run(901, 902, 25, verbose=False) >= 45
     assert not fz.failures, fz.failures[:3]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("log2n", [14, 15, 16, 17, 19, 20, 22])
+def test_real_input_above_one_lds_residency_packed_route(fa, dtype, log2n, monkeypatch):
+    """np.fft.fft of real float32 / float64 signals (final2.py:142-143 with a real f_t) at lengths whose
+    half-length transform still takes several passes: the packed route (n/2 complex samples, then the split
+    into the n bins), against numpy in float64 -- plain, batched, and with the apps' own flag set (Hann over
+    zero-padded samples, power spectrum, statistics); and against the route that promotes to complex."""
+    n = 1 << log2n
+    rdt = np.float32 if dtype == 0 else np.float64
+    tol = TOL[dtype]
+    rng = np.random.default_rng(log2n + 40 * dtype)
+    batch = 3 if log2n <= 17 else 1
+    x = rng.standard_normal((batch, n)).astype(rdt)
+    ref = np.fft.fft(x.astype(np.float64), axis=-1)
+    packed = log2n >= (20 if dtype == 0 else 15)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
+        y = p.exec_host(x, scale=0.5)
+        launches = p.launches
+    assert y.dtype == (np.complex64 if dtype == 0 else np.complex128)
+    assert rel_l2(y, 0.5 * ref) < tol, (n, dtype)
+    # Hermitian symmetry of a real signal's spectrum is exact on the packed route (both halves from one value)
+    if packed:
+        assert np.array_equal(y[:, 1:n // 2], np.conj(y[:, :n // 2:-1]))
+    n_in = n - 1000
+    xw = x[:, :n_in].astype(np.float64) * np.hanning(n_in)
+    ref_s = np.abs(0.25 * np.fft.fft(xw, n=n, axis=-1)) ** 2
+    with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=fa.REAL_IN | fa.HANN | fa.POWER | fa.STATS) as p:
+        S, st = p.exec_host(np.ascontiguousarray(x[:, :n_in]), scale=0.25)
+    assert rel_l2(S, ref_s) < tol
+    f = np.fft.fftfreq(n) * n
+    stol = 1e-5 if dtype == 0 else 1e-11
+    np.testing.assert_allclose(st[:, 0], ref_s.max(axis=1), rtol=stol)
+    np.testing.assert_allclose(st[:, 1], ref_s.sum(axis=1), rtol=stol)
+    np.testing.assert_allclose(st[:, 2], (ref_s * f).sum(axis=1), rtol=0, atol=stol * np.abs(ref_s * f).sum(axis=1).max())
+    # odd sample counts keep the promoting route; so does MFFT_NO_R2C=1 (read when the plan is built)
+    with fa.Plan(n, n_in=n_in - 1, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
+        y_odd = p.exec_host(np.ascontiguousarray(x[:, :n_in - 1]))
+    assert rel_l2(y_odd, np.fft.fft(x[:, :n_in - 1].astype(np.float64), n=n, axis=-1)) < tol
+    monkeypatch.setenv("MFFT_NO_R2C", "1")
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
+        y2 = p.exec_host(x, scale=0.5)
+        assert launches >= 1 and p.launches >= 1
+    monkeypatch.delenv("MFFT_NO_R2C")
+    assert rel_l2(y2, 0.5 * ref) < tol
+    # the numpy-compatible entry point takes the same route
+    assert rel_l2(fa.fft(x[0]), ref[0]) < tol
