@@ -28,7 +28,7 @@
 #define MFFT_TW_SRC 1        // fast variants: twiddles from 0 = global (L1/L2), 1 = registers, 2 = LDS table
 #endif
 #ifndef MFFT_WIN_SRC
-#define MFFT_WIN_SRC 0       // hann variant: window from 0 = registers, 1 = LDS table, 2 = global (L1/L2)
+#define MFFT_WIN_SRC 0       // hann variant: window from 0 = registers, 2 = global (L1/L2)
 #endif
 #ifndef MFFT_WAVES_PER_EU
 #define MFFT_WAVES_PER_EU 0  // 0 = let the compiler choose; k = cap VGPRs for k waves per SIMD
@@ -54,9 +54,6 @@
 #ifndef MFFT_PREFETCH
 #define MFFT_PREFETCH -1     // fast variants load the next signal before transforming the current one: -1 = where measured faster
 #endif                       // (prefetch_default), 0 = never, bit 0 = signals inside one wave, bit 1 = signals spanning several waves
-#ifndef MFFT_TW16_SPLIT
-#define MFFT_TW16_SPLIT 1    // radix-16 passes keep w^1,w^2,w^3,w^4,w^8,w^12 and form the other nine by one multiply
-#endif
 #ifndef MFFT_DIAG_NOFFT
 #define MFFT_DIAG_NOFFT 0    // diagnostic builds only: skip the passes (load -> epilogue -> store) to price the memory side
 #endif
@@ -106,7 +103,7 @@ __device__ unsigned long long g_diag_stamps[16 * 2048];
 #endif
 
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_LDSC = 3 };   // TW_LDSC: LDS table, large passes keep w^1 and w^4 only
-enum { WIN_REG = 0, WIN_LDS = 1, WIN_GLOBAL = 2, WIN_BUF = 3 };
+enum { WIN_REG = 0, WIN_GLOBAL = 2, WIN_BUF = 3 };
 
 // Waves per SIMD the register allocator must leave room for (1 = no constraint).  In its
 // 16-point-per-thread form (MFFT_P8192 = 16) the 8192-point complex64 kernel (512 threads, 68 KiB of
@@ -231,7 +228,7 @@ template <int LEFT> __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LEFT) : "memory");
 }
 
-template <int R0, int R1, int R2, int R3, bool SPLIT16 = (MFFT_TW16_SPLIT != 0)> struct Radices {
+template <int R0, int R1, int R2, int R3, bool SPLIT16 = true> struct Radices {
     static constexpr int r[4] = {R0, R1, R2, R3};
     static constexpr bool split16 = SPLIT16;   // radix-16 passes keep six twiddle generators (see tw_rows)
     static constexpr int npass = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
@@ -474,7 +471,6 @@ template <typename T, class RD, int TX, int P, int VAR> constexpr size_t table_l
 {
     size_t b = 0;
     if (tw_source<T, RD, TX, P, VAR>() == TW_LDS) b += (size_t)tw_total_elems<RD>() * sizeof(cx<T>);
-    if ((VAR == V_HANN_POWER || VAR == V_WIN || VAR == V_HANN_POWER_STATS) && MFFT_WIN_SRC == WIN_LDS) b += (size_t)RD::n * sizeof(T);
     return b;
 }
 
@@ -570,7 +566,6 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
     // ---- tables shared by the workgroup, staged in LDS behind the data slots --
     C* twl = DMA ? reinterpret_cast<C*>(smem_raw + DMA_TABLES_AT)
                  : reinterpret_cast<C*>(smem_raw) + (size_t)SLOTS * LDS_ELEMS;
-    T* winl = reinterpret_cast<T*>(twl + (TWSRC == TW_LDS ? tw_total_elems<RD>() : 0));
     if constexpr (TWSRC == TW_LDS) {
         for (int i = threadIdx.x; i < tw_total_elems<RD>(); i += BLOCK) twl[i] = a.tw[i];
     }
@@ -580,10 +575,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         fill_twc<T, RD, 3, BLOCK>(twl, a.tw);
         __syncthreads();
     }
-    if constexpr (FASTWIN && WINSRC == WIN_LDS) {
-        for (int i = threadIdx.x; i < N; i += BLOCK) winl[i] = a.win[i];
-    }
-    if constexpr (TWSRC == TW_LDS || (FASTWIN && WINSRC == WIN_LDS)) __syncthreads();
+    if constexpr (TWSRC == TW_LDS) __syncthreads();
 
     // ---- per-lane constants, fetched once ---------------------------------
     T wreg[(FASTWIN && WINSRC == WIN_REG) ? P : 1];
@@ -723,7 +715,6 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                     T w;
                     if constexpr (WINSRC == WIN_REG) w = wreg[e];
                     else if constexpr (WINSRC == WIN_BUF) w = buf_ld<T>(make_rsrc(a.win, (uint32_t)N * sizeof(T)), (uint32_t)t * sizeof(T), TX * e * sizeof(T));
-                    else if constexpr (WINSRC == WIN_LDS) w = winl[t + TX * e];
                     else w = a.win[t + TX * e];
                     v[e].x *= w;
                     v[e].y *= w;
@@ -1087,20 +1078,10 @@ template <> struct SizeCfg<10> { static constexpr int P = 16; using RD = Radices
 template <> struct SizeCfg<11> { static constexpr int P = 16; using RD = Radices<8, 16, 16, 1>; };
 template <> struct SizeCfg<12> { static constexpr int P = 16; using RD = Radices<16, 16, 16, 1>; };
 template <> struct SizeCfg<13> { static constexpr int P = 16; using RD = Radices<2, 16, 16, 16>; };
-// 16384 points: 16 per thread in a 1024-thread workgroup (4*16*16*16), or 32 per thread in a
-// 512-thread one with radix-32 first and last passes (32*16*32).  One workgroup fits a CU either
-// way; the 32-point form measured slower where it matters: plain 4.13 against 4.44 TB/s, windowed
-// 2.4 against 3.9, Hann + power equal, power only 3.6 against 3.2.
-#ifndef MFFT_P16384
-#define MFFT_P16384 16
-#endif
-#if MFFT_P16384 == 32
-template <> struct SizeCfg<14> { static constexpr int P = 32; using RD = Radices<32, 16, 32, 1>; };
-#elif MFFT_P16384 == 33     // 32 points per thread, radix-16 butterflies only (smaller working set)
-template <> struct SizeCfg<14> { static constexpr int P = 32; using RD = Radices<4, 16, 16, 16>; };
-#else
+// 16384 points: 16 per thread in a 1024-thread workgroup (4*16*16*16).  (32 per thread in a 512-thread one,
+// with radix-32 first and last passes or with radix-16 butterflies only, measured slower where it matters:
+// plain 4.13 against 4.44 TB/s, windowed 2.4 against 3.9.)
 template <> struct SizeCfg<14> { static constexpr int P = 16; using RD = Radices<4, 16, 16, 16>; };
-#endif
 
 // Per-precision exceptions.  8192 complex64 points: 32 points per thread and a radix-32 first pass.
 // With 16 points a signal needs a 512-thread workgroup and three LDS exchanges (2*16*16*16); the
@@ -1122,7 +1103,7 @@ constexpr int kPadShift = 4;   // one spare element per 16: conflict-free ds_wri
 // spill, 3.0 TB/s against 3.9; the fast variants measured the other way round (4.5 against 3.8).
 template <typename T, int LOG2N, int VAR> constexpr int points_per_thread()
 {
-    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeFor<T, LOG2N>::P;   // (any MFFT_P16384)
+    return (LOG2N == 14 && (VAR == V_GEN_CPLX || VAR == V_GEN_POWER)) ? 32 : SizeFor<T, LOG2N>::P;
 }
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> struct BlockCfg {

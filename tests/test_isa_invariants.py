@@ -67,10 +67,19 @@ def _functions(disasm):
     return funcs
 
 
+def _need_tools():
+    """The checks below guard results, not speed: where the library was built the ROCm LLVM tools exist, so their
+    absence is a failure, not a reason to skip (MFFT_ALLOW_NO_LLVM_TOOLS=1 turns it into a skip on purpose)."""
+    missing = [t for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump") if not _tool(t)]
+    if missing:
+        if os.environ.get("MFFT_ALLOW_NO_LLVM_TOOLS") == "1":
+            pytest.skip(f"ROCm LLVM tools not found: {missing}")
+        pytest.fail(f"ROCm LLVM tools not found ({missing}): the machine-code invariants of libmfft.so cannot be checked")
+
+
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libmfft.so is not built")
-@pytest.mark.skipif(not all(_tool(t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")),
-                    reason="ROCm LLVM tools not found")
 def test_lds_dma_kernels_keep_their_counted_wait(tmp_path):
+    _need_tools()
     objdump = _tool("llvm-objdump")
     checked = 0
     for co in _code_objects(tmp_path):
@@ -103,14 +112,13 @@ def test_lds_dma_kernels_keep_their_counted_wait(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libmfft.so is not built")
-@pytest.mark.skipif(not all(_tool(t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")),
-                    reason="ROCm LLVM tools not found")
 def test_prefetching_tile_kernels_request_the_next_tile_between_exchanges(tmp_path):
     """The 512-point complex128 tile passes (fft_amd/csrc/tile_kernel.h, PF) run one workgroup per CU and
-    overlap its phases by requesting the next tile into a second register set behind the first exchange.
-    That holds only while the request stays between two exchanges' barriers (a __syncthreads() fence or
+    overlap its phases by requesting the next tile into a second register set behind the first exchange;
+    so do the 1024 x 8 and 2048 x 4 ones of the three-pass plans.  That holds only while the request stays between two exchanges' barriers (a __syncthreads() fence or
     a compiler that sinks the loads to their use would undo it), the barriers are LDS-only, and the
     kernels fit 256 registers without spilling inside the loop."""
+    _need_tools()
     objdump = _tool("llvm-objdump")
     checked = 0
     for co in _code_objects(tmp_path):
@@ -119,8 +127,9 @@ def test_prefetching_tile_kernels_request_the_next_tile_between_exchanges(tmp_pa
             continue
         dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True, check=True).stdout
         for name, (_, ins) in _functions(dis).items():
-            m = re.search(r"fft_tile_kernelIdLi9ELi4ELi(\d)E", name)
-            if not m or int(m.group(1)) not in (0, 1, 3, 5, 6, 7):    # dense input: middle, first, last, last + power, last + twiddle, first + window
+            m = re.search(r"fft_tile_kernelId(Li9ELi4|Li10ELi3|Li11ELi2)ELi(\d)E", name)
+            # dense input: middle, first, last, last + power, last + twiddle; the 512-point tiles also first + window
+            if not m or int(m.group(2)) not in ((0, 1, 3, 5, 6, 7) if m.group(1) == "Li9ELi4" else (0, 1, 3, 5, 6)):
                 continue
             checked += 1
             back = [(adr - tgt, tgt, adr) for adr, _, tgt in ins if tgt is not None and tgt < adr]
@@ -137,4 +146,36 @@ def test_prefetching_tile_kernels_request_the_next_tile_between_exchanges(tmp_pa
             for b in bars:
                 window = " ".join(body[max(0, b - 3):b])
                 assert "vmcnt(0)" not in window, (name, "a barrier of the exchange drains the vector-memory counter")
-    assert checked >= 6, f"only {checked} prefetching tile kernels found in {LIB}"
+    assert checked >= 16, f"only {checked} prefetching tile kernels found in {LIB}"
+
+
+# Non-default values of the kernels' MFFT_* build macros (A/B builds: make VARIANT=x KNOBS="-D...").  The default
+# build never takes these branches, so they are type-checked here: three syntax-only device compiles of a
+# translation unit that instantiates every variant of a few sizes of each kernel family (a few seconds each).
+KNOB_SETS = [
+    "-DMFFT_TW_SRC=2 -DMFFT_WIN_SRC=2 -DMFFT_PREFETCH=3 -DMFFT_AFFINE=1 -DMFFT_VEC=1 -DMFFT_FAST_BUF=1 -DMFFT_TILE_EVAL_ROOTS=1 "
+    "-DMFFT_BIG_RADIX=1 -DMFFT_TILE_PF_GEN=1 -DMFFT_P8192=16 -DMFFT_WAVES_PER_EU=2 -DMFFT_BLOCK_MIN=128 -DMFFT_WIN_BUF_FROM=4096 "
+    "-DMFFT_WAVE_UNROLL=2",
+    "-DMFFT_TW_SRC=0 -DMFFT_PREFETCH=0 -DMFFT_AFFINE=0 -DMFFT_VEC=0 -DMFFT_NT=0 -DMFFT_DMA=0 -DMFFT_TILE_TW2=0 -DMFFT_TILE_VEC=0 "
+    "-DMFFT_TILE_EVAL_ROOTS=0 -DMFFT_TILE_PREFETCH=0 -DMFFT_TILE_OCC=0 -DMFFT_STATS_F32=0 -DMFFT_STATS_CLOSED=0 "
+    "-DMFFT_DMA_STATS_LDS=0 -DMFFT_DMA_WARM=0 -DMFFT_BLOCK_2048=0 -DMFFT_C128_1024_COLS=2 -DMFFT_TILE_PF_HANN=0 -DMFFT_TILE_PF_POWER=0",
+    "-DMFFT_DIAG_NOFFT=1 -DMFFT_DIAG_SKIP=3 -DMFFT_DIAG_STAMPS=1",
+]
+
+
+@pytest.mark.parametrize("knobs", KNOB_SETS)
+def test_build_knobs_still_compile(knobs):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = os.path.join(ROOT, "tools", "csrc", "knob_check.hip")
+    r = subprocess.run([hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "--cuda-device-only", "-fsyntax-only",
+                        "-Wno-unused-function", *knobs.split(), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # every macro the kernels' headers define as a knob is named by one of the sets (a new knob needs a line here)
+    defined = set()
+    for h in ("lds_kernel.h", "tile_kernel.h", "wave_kernel.h"):
+        with open(os.path.join(ROOT, "fft_amd", "csrc", h)) as fh:
+            defined |= set(re.findall(r"^#ifndef (MFFT_[A-Z0-9_]+)\n#define \1 ", fh.read(), re.M))
+    named = set(re.findall(r"-D(MFFT_[A-Z0-9_]+)=", " ".join(KNOB_SETS)))
+    assert defined - named <= {"MFFT_R1024"}, sorted(defined - named)

@@ -26,7 +26,25 @@ def best(f, reps=5):
     return b
 
 
+def loop(calls):
+    """`calls` executions of fft_from_timeseries at final2's defaults and nothing else: the workload of a kernel
+    timeline (tools/trace_app.sh) or of `python -m cProfile -s tottime tools/app_bench.py --loop 300`."""
+    n0, pad, dt = 8001, 32, 0.01
+    times = np.arange(n0) * dt
+    f_t = so.return_amplitude_block([1, 1, 1], [1, 1], 1, 0, times)
+    kw = dict(n_levels=3, pad_factor=pad, include_dc=True, guard_mult=2.0, min_weight=1e-5, keep_top=3)
+    for _ in range(20):
+        fft_amd.fft_from_timeseries(f_t, times, **kw)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        fft_amd.fft_from_timeseries(f_t, times, **kw)
+    print(f"plain loop: {(time.perf_counter() - t0) / calls * 1e3:.3f} ms per call")
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--loop":
+        torch.cuda.set_device(0)
+        return loop(int(sys.argv[2]))
     torch.cuda.set_device(0)
     stream = torch.cuda.current_stream().cuda_stream
     for n0, pad in ((8001, 32), (1501, 16), (8001, 64)):

@@ -1,8 +1,10 @@
+#!/bin/bash
+# Kernel timeline of one fft_from_timeseries call at final2's defaults (rocprofv3 --kernel-trace), on the GPU box.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pa
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pa -o t -- python3 $R/tools/app_profile.py 60 > /tmp/pa.log 2>&1 || { tail -n 5 /tmp/pa.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pa -o t -- python3 $R/tools/app_bench.py --loop 60 > /tmp/pa.log 2>&1 || { tail -n 5 /tmp/pa.log; exit 1; }
 f=$(find /tmp/pa -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
