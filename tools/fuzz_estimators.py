@@ -27,6 +27,7 @@ worst = {"E": 0.0, "p": 0.0, "S": 0.0}
 # reference gives for one of the perturbed inputs (i.e. one of the reference's own answers at rounding level).
 ties = {"ill_posed": 0, "same_as_reference": 0, "same_as_a_perturbed_reference": 0, "neither": 0}
 _alternates = []
+neither = []
 
 
 def compare(tag, got, ref, case, etol=1e-8, ptol=1e-6, stol=1e-11):
@@ -97,6 +98,7 @@ def judge(tag, got, ref, case, posed, **tol):
             ties["same_as_a_perturbed_reference"] += 1
         else:
             ties["neither"] += 1
+            neither.append((tag, [np.round(a[0], 6).tolist() for a in [got, ref] + list(_alternates)]) + tuple(case[:4]))
     if len(failures) > before and not posed:
         unstable.extend(failures[before:])
         del failures[before:]
@@ -181,4 +183,6 @@ if __name__ == "__main__":
     print("fuzz_estimators", "ok" if not failures else "MISMATCHES", count, "cases; worst |dE| %.2e  |dp| %.2e  rel L2 S %.2e"
           % (worst["E"], worst["p"], worst["S"]))
     print("inputs whose reference answer flips under a 1e-13 perturbation:", ties)
+    for item in neither:
+        print("NEITHER (GPU lines, reference lines, perturbed references' lines)", item)
     sys.exit(1 if failures else 0)
