@@ -258,8 +258,9 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
     // complex128 signals of 2^28 .. 2^31 points: three passes through the 1024 x 8 tiles (128-byte rows, 4.4-4.9
     // TB/s per pass against 5.0-5.3 for the 256-byte rows of the 512 x 16 ones) instead of four through narrower
     // radices -- 2^28 6.82 -> 5.21 ms as 1024 * 512 * 512, 2^29 13.6 -> 10.9 as 1024 * 1024 * 512, 2^30 27.7 -> 24.2
-    // as 1024^3; 2^31 needs one 2048 x 4 pass (64-byte rows: 2.7-2.9 TB/s), last, where it costs least:
-    // 54.4 -> 52.8 ms (2048 first: 58.1).  Alternated with the four-pass splits in one process.
+    // as 1024^3; 2^31 needs one 2048 x 4 pass (64-byte rows: 2.7-2.9 TB/s), first, where its output is one
+    // contiguous run per tile: 54.5 -> 51.9 ms (2048 in the middle or last: 53.4).  Alternated with the
+    // four-pass splits in one process.
     if (!log2_inner && dtype == MFFT_C128 && log2n >= 28 && log2n <= 31 && !getenv("MFFT_FOUR_PASSES")) {
         const int third = log2n - 20;                     // 8 .. 11
         if (third <= 10) {                                // (10, 9, 9), (10, 10, 9), (10, 10, 10)
@@ -267,9 +268,9 @@ static int choose_split(int log2n, int dtype, std::vector<int>* out, int log2_in
             out->push_back(third >= 9 ? 10 : 9);
             out->push_back(third >= 10 ? 10 : 9);
         } else {
-            out->push_back(10);
-            out->push_back(10);
             out->push_back(11);
+            out->push_back(10);
+            out->push_back(10);
         }
         return MFFT_OK;
     }

@@ -141,7 +141,7 @@ def test_largest_app_length():
 
 def test_cfg5_2pow31_c128_single_plan():
     """The same 2^31-point complex128 transform as ONE plan on one GPU: three global passes
-    (1024 * 1024 * 2048), natural-order output, 32 GiB of workspace."""
+    (2048 * 1024 * 1024), natural-order output, 32 GiB of workspace."""
     import torch
     import fft_amd as fa
     torch.cuda.set_device(0)
