@@ -574,7 +574,11 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         if constexpr (sizeof(T) == 8)
             in_hann = (io.win || io.n_in < n) && !io.win_pairs && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
                       inner == 1 && !(narrow & 1) && tile_first_hann_c128(gp.log2g) && !table_window;
-        int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : TM_FIRST_GEN))
+        // dense complex samples times at most one table, zero-padded: the lean prologue (the apps' chirp-z, demodulating
+        // and windowed plans); real input, conjugation, segments and pair windows keep the general one
+        const bool in_pre = !io.real_in && !io.conj_in && io.in_seg == 0 && !io.win_pairs && !(io.win && io.pre) &&
+                            io.n_in >= 1 && io.n_in <= n && !getenv("MFFT_GENERAL_PROLOGUE");
+        int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : (in_pre ? TM_FIRST_PRE : TM_FIRST_GEN)))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
         if (inner > 1) {
             // column-batched: every pass is a strided-in / strided-out pass (the first one with

@@ -194,7 +194,9 @@ __device__ __forceinline__ cx<double> tile_turn(double f)
 // data and nothing fused; *_GEN / LAST_POWER carry the runtime prologue / epilogue.
 enum TileMode { TM_MID = 0, TM_FIRST_PLAIN = 1, TM_FIRST_GEN = 2, TM_LAST_PLAIN = 3, TM_LAST_GEN = 4,
                 TM_LAST_POWER = 5, TM_LAST_TWID = 6,
-                TM_FIRST_HANN = 7 };   // dense complex input of n_in <= N samples, Hann window evaluated, zero padding (prefetching tiles only)
+                TM_FIRST_HANN = 7,     // dense complex input of n_in <= N samples, Hann window evaluated, zero padding (prefetching tiles only)
+                TM_FIRST_PRE = 8 };    // dense complex input of n_in <= N samples times ONE table (complex premultiplier or real window, or
+                                       // none), zero padding: what the apps' own calls need (chirp-z, demodulation, window), 32-bit indices
 
 // Columns per tile.  Wide (default): 512-byte rows where LDS allows -- 64 complex64 columns up to
 // 128-point tiles, 32 at 256 points, 16 at 512; 32 complex128 columns up to 256 points, 16 at 512.
@@ -290,7 +292,7 @@ template <typename T, int LOG2G, int LOG2C, int MODE>
 __global__ void __launch_bounds__(((TileCfg<T, LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<T, LOG2G>::TX) << LOG2C), MODE>()))
 fft_tile_kernel(const TArgs<T> a)
 {
-    constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN || MODE == TM_FIRST_HANN);
+    constexpr bool FIRST = (MODE == TM_FIRST_PLAIN || MODE == TM_FIRST_GEN || MODE == TM_FIRST_HANN || MODE == TM_FIRST_PRE);
     using C_ = cx<T>;
     using TC = TileCfg<T, LOG2G>;
     using RD = typename TC::RD;
@@ -420,6 +422,26 @@ fft_tile_kernel(const TArgs<T> a)
                 v[e].x = (T)((double)v[e].x * wv);
                 v[e].y = (T)((double)v[e].y * wv);
                 z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};
+            }
+        } else if constexpr (MODE == TM_FIRST_PRE) {
+            // sample index of v[e]: i0 + e * istep < N <= 2^31.  Loads and table reads are issued unconditionally at
+            // the index clamped to the last sample (they stay in flight together); samples past it are zeroed.
+            const uint32_t last = (uint32_t)(a.n_in - 1);
+            const uint32_t i0 = (uint32_t)j + (uint32_t)t * (uint32_t)a.L, istep = (uint32_t)TX * (uint32_t)a.L;
+            const C_* __restrict__ sig = reinterpret_cast<const C_*>(a.in) + b * a.in_stride;
+            const auto at = [&](int e) { const uint32_t i = i0 + (uint32_t)e * istep; return i < last ? i : last; };
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = sig[at(e)];
+            if (a.pre) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = cmul(v[e], a.pre[at(e)]);
+            } else if (a.win) {
+#pragma unroll
+                for (int e = 0; e < P; ++e) { const T wv = a.win[at(e)]; v[e].x *= wv; v[e].y *= wv; }
+            }
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                if (i0 + (uint32_t)e * istep > last) v[e] = C_{0, 0};             // zero padding
             }
         } else if constexpr (MODE == TM_FIRST_GEN) {
             // runtime prologue: unconditional loads at clamped indices, options as uniform
@@ -782,6 +804,7 @@ int launch_tile_modes_at(int mode, const TArgs<T>& a, hipStream_t s)
     case TM_MID: return launch_tile_one<T, LOG2G, LC, TM_MID>(a, s);
     case TM_FIRST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_PLAIN>(a, s);
     case TM_FIRST_GEN: return launch_tile_one<T, LOG2G, LC, TM_FIRST_GEN>(a, s);
+    case TM_FIRST_PRE: return launch_tile_one<T, LOG2G, LC, TM_FIRST_PRE>(a, s);
     case TM_LAST_PLAIN: return launch_tile_one<T, LOG2G, LC, TM_LAST_PLAIN>(a, s);
     case TM_LAST_GEN: return launch_tile_one<T, LOG2G, LC, TM_LAST_GEN>(a, s);
     case TM_LAST_POWER: return launch_tile_one<T, LOG2G, LC, TM_LAST_POWER>(a, s);
