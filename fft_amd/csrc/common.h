@@ -141,6 +141,7 @@ int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile fo
 int tile_log2c_c128(int log2g, int narrow);
 bool tile_geometry_c64(int log2g, LdsGeometry* g);    // radices and table shape of a tile's column transforms
 bool tile_geometry_c128(int log2g, LdsGeometry* g);
-bool tile_first_hann_c128(int log2g);         // is there a first pass that evaluates the Hann window (TM_FIRST_HANN) at this radix?
+bool tile_first_hann_c64();                    // is the first pass that evaluates the Hann window (TM_FIRST_HANN) built?
+bool tile_first_hann_c128();
 
 }  // namespace mfft

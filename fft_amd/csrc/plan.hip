@@ -197,6 +197,7 @@ struct Pow2Engine {
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
     int narrow = 0;                     // tile width bits (TArgs::narrow)
+    int tile_buf = -1;                  // MFFT_TILE_BUF at build (tuning aid): TArgs::buf of every pass; -1 = by tile width and data size
     bool table_window = false;          // MFFT_TABLE_WINDOW at build: windowed first passes read the window table (tuning aid)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
     int64_t fs_n = 0, fs_c0 = 0;        // four-step twiddle exp(-2 pi i k (c0 + c) / fs_n) on the output, 0 = none
@@ -305,6 +306,7 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     n = n_; batch = batch_; dtype = dtype_; inner = inner_; fs_n = fs_n_; fs_c0 = fs_c0_;
     log2n = ilog2(n);
     table_window = getenv("MFFT_TABLE_WINDOW") != nullptr;
+    if (const char* e = getenv("MFFT_TILE_BUF")) tile_buf = atoi(e);
     if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
     if (!is_pow2(inner)) { set_error("the inner extent of a column-batched transform must be a power of two"); return MFFT_E_UNSUPPORTED; }
     const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
@@ -555,6 +557,9 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.nt = (p < 4 && tile_nt_pass[p] >= 0) ? tile_nt_pass[p] : tile_nt;
         a.xcd = tile_log2c(dtype, gp.log2g, narrow) <= 2 ? 1 : 0;   // four-column tiles: neighbours share cache lines,
         if (a.xcd) a.nt = 0;                                         // which streaming accesses would not keep in L2
+        // buffer-form accesses: four-column tiles always, wider ones while the plan's data is at most 128 MiB
+        a.buf = tile_buf >= 0 ? tile_buf
+                              : ((tile_log2c(dtype, gp.log2g, narrow) <= 2 || (inner == 1 && work_bytes <= (size_t(128) << 20))) ? 12 : 0);
         a.scale = 1;
         if (first) {
             a.win = io.win; a.pre = io.pre; a.n_in = io.n_in;
@@ -569,15 +574,14 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         }
         const bool in_plain = !io.win && !io.pre && !io.real_in && !io.conj_in && io.n_in == n && io.in_seg == 0;
         const bool out_plain = !io.post && !io.stats && !io.conj_out && io.n_out == n && io.out_seg == 0 && !io.power;
-        // dense complex samples under the Hann window and / or zero-padded into prefetching tiles: window evaluated
-        bool in_hann = false;
-        if constexpr (sizeof(T) == 8)
-            in_hann = (io.win || io.n_in < n) && !io.win_pairs && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 && io.n_in >= 2 && io.n_in <= n &&
-                      inner == 1 && !(narrow & 1) && tile_first_hann_c128(gp.log2g) && !table_window;
-        // dense complex samples times at most one table, zero-padded: the lean prologue (the apps' chirp-z, demodulating
-        // and windowed plans); real input, conjugation, segments and pair windows keep the general one
+        // dense complex samples under the Hann window and / or zero-padded: the window is evaluated, no table read
+        const bool in_hann = (io.win || io.n_in < n) && !io.win_pairs && !io.pre && !io.real_in && !io.conj_in && io.in_seg == 0 &&
+                             io.n_in >= 2 && io.n_in <= n && n * (int64_t)sizeof(cx<T>) < (int64_t(1) << 32) && inner == 1 && !(narrow & 1) &&
+                             (sizeof(T) == 8 ? tile_first_hann_c128() : tile_first_hann_c64()) && !table_window;
+        // dense complex samples times at most one table, zero-padded: the lean prologue (the apps' chirp-z and
+        // demodulating plans); real input, conjugation, segments and pair windows keep the general one
         const bool in_pre = !io.real_in && !io.conj_in && io.in_seg == 0 && !io.win_pairs && !(io.win && io.pre) &&
-                            io.n_in >= 1 && io.n_in <= n && !getenv("MFFT_GENERAL_PROLOGUE");
+                            io.n_in >= 1 && io.n_in <= n && n <= (int64_t(1) << 31) && !getenv("MFFT_GENERAL_PROLOGUE");
         int mode = first ? (in_plain ? TM_FIRST_PLAIN : (in_hann ? TM_FIRST_HANN : (in_pre ? TM_FIRST_PRE : TM_FIRST_GEN)))
                          : (last ? (io.power ? TM_LAST_POWER : (out_plain ? TM_LAST_PLAIN : TM_LAST_GEN)) : TM_MID);
         if (inner > 1) {

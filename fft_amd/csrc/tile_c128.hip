@@ -8,5 +8,5 @@ int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s)
 }
 int tile_log2c_c128(int log2g, int narrow) { return tile_log2c_for<double>(log2g, narrow); }
 bool tile_geometry_c128(int log2g, LdsGeometry* g) { return tile_geometry_for<double>(log2g, g); }
-bool tile_first_hann_c128(int log2g) { return log2g == 9 && tile_first_hann<double, 9>(); }
+bool tile_first_hann_c128() { return tile_first_hann<double, 9>(); }
 }  // namespace mfft

@@ -8,4 +8,5 @@ int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s)
 }
 int tile_log2c_c64(int log2g, int narrow) { return tile_log2c_for<float>(log2g, narrow); }
 bool tile_geometry_c64(int log2g, LdsGeometry* g) { return tile_geometry_for<float>(log2g, g); }
+bool tile_first_hann_c64() { return tile_first_hann<float, 9>(); }
 }  // namespace mfft

@@ -41,8 +41,8 @@
 #endif
 
 #ifndef MFFT_TILE_PF_HANN
-#define MFFT_TILE_PF_HANN 1 // the first pass of a Hann-windowed (and zero-padded) complex128 transform whose tiles are 512 points
-                            // prefetches too, evaluating the window per thread (TM_FIRST_HANN) instead of reading its table
+#define MFFT_TILE_PF_HANN 1 // the first pass of a Hann-windowed (and / or zero-padded) transform evaluates the window per thread
+                            // (TM_FIRST_HANN) instead of reading its table -- so the prefetching tiles can prefetch there too
 #endif
 
 #ifndef MFFT_TILE_PF_GEN
@@ -120,6 +120,11 @@ template <typename T> struct TArgs {
     int narrow;           // tile width bits (see launch_tile_mode)
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
+    int buf;              // plain loads (bit 2) / four-column tiles' plain stores (bit 3) as buffer instructions: the tile's origin
+                          // in the descriptor, the row group in the scalar offset, one 32-bit lane offset.  Needs a signal of
+                          // less than 2^32 bytes (checked at launch).  Measured on MI355X against global loads with a scalar
+                          // base: four-column tiles +1..7 % (2^19 x 128 complex64 526 -> 491 us), wider tiles +1.5..3.6 %
+                          // (complex64) / 0..1.4 % (complex128) while the plan's data is at most 128 MiB and -4..5 % beyond
     T scale;
     // FIRST_HANN: the window 0.5 - 0.5 cos(2 pi i / (n_in - 1)) is evaluated from the turn fraction i * win_inv_m;
     // win_step = ((TX * L) mod (n_in - 1)) / (n_in - 1), the fraction between a thread's consecutive samples
@@ -284,7 +289,8 @@ __device__ __forceinline__ void tile_exchange(cx<T> (&v)[P], int t, int c, cx<T>
 // bytes per lane) lost up to 11 %, so it keeps the compiler's own allocation.
 template <typename T, int BLOCK, int MODE> constexpr int tile_min_waves()
 {
-    constexpr bool plain = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID;
+    constexpr bool plain = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
+                           MODE == TM_FIRST_HANN;
     return (MFFT_TILE_OCC != 0 && sizeof(T) == 4 && plain && BLOCK <= 512) ? BLOCK / 128 : 1;
 }
 
@@ -394,6 +400,17 @@ fft_tile_kernel(const TArgs<T> a)
         if constexpr (MODE == TM_FIRST_PLAIN) {
             if constexpr (PF) {
                 // loaded above / by the previous trip
+            } else if (a.buf & 4) {
+                // buffer form: the tile's origin in the descriptor, the row group in the scalar offset, one lane offset
+                const auto rs = make_rsrc(in_base, 0xffffffffu);
+                const uint32_t voff = lane_in * (uint32_t)sizeof(C_), sstep = (uint32_t)pstep * (uint32_t)sizeof(C_);
+                if (a.nt & 1) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 2>(rs, voff, (uint32_t)e * sstep);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 0>(rs, voff, (uint32_t)e * sstep);
+                }
             } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
@@ -408,20 +425,51 @@ fft_tile_kernel(const TArgs<T> a)
                 }
             }
         } else if constexpr (MODE == TM_FIRST_HANN) {
-            static_assert(MODE != TM_FIRST_HANN || PF, "the evaluated-window first pass exists for the prefetching tiles only");
-            // samples requested above / by the previous trip.  Window of sample i = i0 + e*pstep: the point
+            // samples: requested above / by the previous trip (prefetching tiles), else loaded here.  Window of sample i = i0 + e*pstep: the point
             // exp(2 pi i * i/(n_in - 1)) is stepped along the thread's constant stride (double recurrence, P steps)
-            const int64_t i0 = j + (int64_t)t * a.L;
-            cx<double> z = tile_turn((double)(i0 < a.n_in ? i0 : 0) * a.win_inv_m);
-            double ws = a.win_step;
-            asm volatile("" : "+v"(ws));       // evaluated per trip: hoisted out of the loop the step costs four registers for its whole length
-            const cx<double> zs = tile_turn(ws);
+            if constexpr (!PF) {
+                // buffer loads: one lane offset, wave-uniform row-group offsets, and the hardware range check returns
+                // zero past the last sample -- zero padding without clamps or predicates (N * sizeof < 2^32)
+                const auto rs = make_rsrc(reinterpret_cast<const C_*>(a.in) + b * a.in_stride, (uint32_t)(a.n_in * (int64_t)sizeof(C_)));
+                const uint32_t voff = ((uint32_t)c + (uint32_t)t * (uint32_t)a.L) * (uint32_t)sizeof(C_);
+                const uint32_t s0 = (uint32_t)j0 * (uint32_t)sizeof(C_), sstep = (uint32_t)TX * (uint32_t)a.L * (uint32_t)sizeof(C_);
+                if (a.nt & 1) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) {
-                const double wv = (i0 + e * pstep < a.n_in) ? (a.win ? fma(-0.5, z.x, 0.5) : 1.0) : 0.0;    // zero padding
-                v[e].x = (T)((double)v[e].x * wv);
-                v[e].y = (T)((double)v[e].y * wv);
-                z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 2>(rs, voff, s0 + (uint32_t)e * sstep);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 0>(rs, voff, s0 + (uint32_t)e * sstep);
+                }
+            }
+            const int64_t i0 = j + (int64_t)t * a.L;
+            if constexpr (!PF) {
+                if (a.win) {      // samples past the last one are zero already
+                    cx<double> z = tile_turn((double)(i0 < a.n_in ? i0 : 0) * a.win_inv_m);
+                    const cx<double> zs = tile_turn(a.win_step);
+#pragma unroll
+                    for (int e = 0; e < P; ++e) {
+                        const double wv = fma(-0.5, z.x, 0.5);
+                        if constexpr (sizeof(T) == 4) {
+                            const float wf = (float)wv;
+                            v[e].x *= wf; v[e].y *= wf;
+                        } else {
+                            v[e].x *= wv; v[e].y *= wv;
+                        }
+                        z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};
+                    }
+                }
+            } else {
+                cx<double> z = tile_turn((double)(i0 < a.n_in ? i0 : 0) * a.win_inv_m);
+                double ws = a.win_step;
+                asm volatile("" : "+v"(ws));       // evaluated per trip: hoisted out of the loop the step costs four registers for its whole length
+                const cx<double> zs = tile_turn(ws);
+#pragma unroll
+                for (int e = 0; e < P; ++e) {
+                    const double wv = (i0 + e * pstep < a.n_in) ? (a.win ? fma(-0.5, z.x, 0.5) : 1.0) : 0.0;    // zero padding
+                    v[e].x = (T)((double)v[e].x * wv);
+                    v[e].y = (T)((double)v[e].y * wv);
+                    z = cx<double>{z.x * zs.x - z.y * zs.y, z.x * zs.y + z.y * zs.x};
+                }
             }
         } else if constexpr (MODE == TM_FIRST_PRE) {
             // sample index of v[e]: i0 + e * istep < N <= 2^31.  Loads and table reads are issued unconditionally at
@@ -497,6 +545,17 @@ fft_tile_kernel(const TArgs<T> a)
         } else {
             if constexpr (PF) {
                 // loaded above / by the previous trip
+            } else if (a.buf & 4) {
+                // buffer form: the tile's origin in the descriptor, the row group in the scalar offset, one lane offset
+                const auto rs = make_rsrc(in_base, 0xffffffffu);
+                const uint32_t voff = lane_in * (uint32_t)sizeof(C_), sstep = (uint32_t)pstep * (uint32_t)sizeof(C_);
+                if (a.nt & 1) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 2>(rs, voff, (uint32_t)e * sstep);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) v[e] = buf_ld<C_, 0>(rs, voff, (uint32_t)e * sstep);
+                }
             } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = tile_ld<T, false>(in_base + e * pstep + lane_in);
@@ -611,7 +670,12 @@ fft_tile_kernel(const TArgs<T> a)
                                         ((j0 >> a.log2_ns) << a.log2_ns) * G + (j0 & ns_mask);
             const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)a.NS;
             const int64_t qstep = (int64_t)TX * a.NS;
-            if constexpr (SLIM4) {
+            if (SLIM4 && (a.buf & 8)) {
+                const auto rs = make_rsrc(out_base, 0xffffffffu);
+                const uint32_t voff = lane_out * (uint32_t)sizeof(C_), sstep = (uint32_t)qstep * (uint32_t)sizeof(C_);
+#pragma unroll
+                for (int e = 0; e < P; ++e) buf_st<C_, 0>(rs, voff, (uint32_t)e * sstep, v[e]);
+            } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) tile_st<T, false>(out_base + e * qstep + lane_out, v[e]);
             } else {
@@ -662,7 +726,12 @@ fft_tile_kernel(const TArgs<T> a)
                                         (j0 & ((int64_t(1) << a.log2_w) - 1));
             const uint32_t lane_out = (uint32_t)c + (uint32_t)t * (uint32_t)nso;
             const int64_t qstep = (int64_t)TX * nso;
-            if constexpr (SLIM4) {
+            if (SLIM4 && (a.buf & 8)) {
+                const auto rs = make_rsrc(out_base, 0xffffffffu);
+                const uint32_t voff = lane_out * (uint32_t)sizeof(C_), sstep = (uint32_t)qstep * (uint32_t)sizeof(C_);
+#pragma unroll
+                for (int e = 0; e < P; ++e) buf_st<C_, 0>(rs, voff, (uint32_t)e * sstep, v[e]);
+            } else if constexpr (SLIM4) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) tile_st<T, false>(out_base + e * qstep + lane_out, v[e]);
             } else {
@@ -785,15 +854,26 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
     const int64_t total = a.batch << a.log2_tiles;
     if (total <= 0) return MFFT_OK;
     const int grid = pick_grid(per_cu, total);
+    if (a.buf) {
+        // byte offsets of the buffer form stay below 2^32: G rows of L elements in, G rows of NS (or out_pitch) out
+        const int64_t nso = (MODE == TM_LAST_PLAIN) ? (a.NS >> a.log2_w) * a.out_pitch : a.NS;
+        const int64_t lim = (int64_t(1) << 32) / (int64_t)sizeof(cx<T>);
+        TArgs<T> h = a;
+        if ((a.L << LOG2G) > lim) h.buf &= ~4;
+        if ((nso << LOG2G) > lim) h.buf &= ~8;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, h);
+        MFFT_HIP(hipGetLastError());
+        return MFFT_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }
 
-// which tiles have the evaluated-window first pass: the prefetching ones (512-point complex128)
+// which tiles have the evaluated-window first pass (all; MFFT_TILE_PF_HANN=0 builds none, for A/B)
 template <typename T, int LOG2G> constexpr bool tile_first_hann()
 {
-    return MFFT_TILE_PF_HANN != 0 && MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && LOG2G == 9;
+    return MFFT_TILE_PF_HANN != 0 && MFFT_DIAG_NOFFT == 0;
 }
 
 // every mode of one radix at one tile width

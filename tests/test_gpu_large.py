@@ -111,6 +111,43 @@ def test_first_pass_with_evaluated_hann_window_against_numpy(fa, monkeypatch, sp
         assert rel_l2(y, np.abs(ref) ** 2 if power else ref) < 1e-13
 
 
+@pytest.mark.parametrize("dtype,split,log2n,batch,n_in,power", [
+    (0, "4,9", 13, 9, 8191, False), (0, "5,9", 14, 5, 9001, True), (0, "6,8", 14, 7, 1 << 14, False), (0, "7,8", 15, 6, 20001, True),
+    (0, "8,9", 17, 5, 100003, False), (0, "9,8", 17, 5, 1 << 17, True), (0, "9,9", 18, 3, 2, False), (0, "10,9", 19, 3, 333333, True),
+    (0, "10,9", 19, 2, 1 << 19, False), (0, "8,8,8", 24, 1, 9000001, True),
+    (1, "4,9", 13, 4, 5000, True), (1, "6,8", 14, 3, 1 << 14, False), (1, "7,9", 16, 5, 40001, False), (1, "8,8", 16, 9, 3, True),
+    (1, "10,9", 19, 2, 400001, True), (1, "10,9", 19, 9, 1 << 19, False), (1, "11,9", 20, 1, 777777, False)])
+def test_first_pass_with_evaluated_window_and_range_checked_loads(fa, monkeypatch, dtype, split, log2n, batch, n_in, power):
+    """np.fft.fft(x * np.hanning(n_in), n) (final2.py:139-143) and np.fft.fft(x, n) where the first pass is any tile
+    other than the prefetching one: the samples come through buffer loads whose range check returns zero past sample
+    n_in - 1 (the zero padding), the window is evaluated per thread.  Every first-pass radix of both precisions, full
+    and padded lengths, odd and tiny sample counts; the table route gives the same spectrum."""
+    monkeypatch.setenv("MFFT_SPLIT", split)
+    n = 1 << log2n
+    cdt, tol = (np.complex64, 1e-5) if dtype == 0 else (np.complex128, 1e-13)
+    x = _rand((batch, n_in), 77 + log2n + batch, cdt)
+    x64 = x.astype(np.complex128)
+    for window in (True, False):
+        if not window and n_in == n:
+            continue                      # that is the plain first pass
+        flags = (fa.HANN if window else 0) | (fa.POWER if power else 0)
+        ref = np.fft.fft(x64 * np.hanning(n_in) if window else x64, n, axis=-1)
+        if power:
+            ref = np.abs(ref) ** 2
+        with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags) as p:
+            y = p.exec_host(x)
+        if np.any(ref):
+            assert rel_l2(y, ref) < tol, (window, rel_l2(y, ref))
+        else:
+            assert not np.any(y)
+        if window:
+            monkeypatch.setenv("MFFT_TABLE_WINDOW", "1")
+            with fa.Plan(n, n_in=n_in, batch=batch, dtype=dtype, flags=flags) as p:
+                yt = p.exec_host(x)
+            monkeypatch.delenv("MFFT_TABLE_WINDOW")
+            assert rel_l2(yt, ref) < tol if np.any(ref) else not np.any(yt)
+
+
 def test_large_complex64_plans_on_sampled_bins(fa):
     """2^26 and 2^27 complex64 points (9,9,8 and 9,9,9: one and two twiddled 512-point passes): sampled bins
     against the DFT evaluated directly in float64, and Parseval."""
