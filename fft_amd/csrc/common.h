@@ -137,6 +137,8 @@ template <typename T> struct TArgs;
 enum { kTileMinLog2G = 4, kTileMaxLog2G = 9, kTileMaxLog2GNarrow = 12 };   // 10..12: four-column tiles (complex128: 1024 x 8 and 2048 x 4)
 int launch_tile_c64(int log2g, int mode, const TArgs<float>& a, hipStream_t s);
 int launch_tile_c128(int log2g, int mode, const TArgs<double>& a, hipStream_t s);
+int launch_tile_r2c_c64(int log2g, const TArgs<float>& a, hipStream_t s);     // last pass of a packed real signal's half-length
+int launch_tile_r2c_c128(int log2g, const TArgs<double>& a, hipStream_t s);   // transform, split into the n bins fused (tile_r2c_kernel.h)
 int tile_log2c_c64(int log2g, int narrow);    // log2 of the columns per tile for this radix and width class (TArgs::narrow bits)
 int tile_log2c_c128(int log2g, int narrow);
 bool tile_geometry_c64(int log2g, LdsGeometry* g);    // radices and table shape of a tile's column transforms

@@ -144,6 +144,8 @@ template <typename T> struct Io {
     int win_pairs = 0;     // `win` weighs the real and the imaginary part of every sample separately (packed real input)
     T scale = 1;
     bool power = false;
+    bool r2c = false;      // the transform is the half-length one of a packed real signal: the last pass splits its bins into the
+                           // 2 n bins of the signal's own spectrum (or their power) at `out`, signals out_stride elements apart
     int64_t batch = 0;     // > 0: transform only this many signals (a slab of the plan's batch)
 };
 
@@ -193,6 +195,7 @@ struct Pow2Engine {
     size_t work_bytes = 0;
     void* stage_in = nullptr;           // dense copies around a general single-kernel transform whose
     void* stage_out = nullptr;          // caller layout is segmented (allocated on first use)
+    void* r2c_side = nullptr;           // fused real-input last pass: raw outputs of the two self-mirrored columns (first use)
     int64_t bytes = 0;                  // device memory held
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
@@ -209,6 +212,15 @@ struct Pow2Engine {
     // exec() derives the statistics of a dense power spectrum from a reduction after the last pass
     // (and so overwrites all of them) whenever the transform takes several passes
     bool stats_by_reduction(bool power, int64_t out_seg) const { return !single && power && out_seg == 0 && work[0] != nullptr; }
+    // can the last pass carry the split of a packed real signal?  (tile passes, two tiles or more per signal at the last radix)
+    bool r2c_fusable() const
+    {
+        if (single || inner != 1 || passes.size() < 2) return false;
+        const int lg = passes.back().log2g;
+        if (dtype == MFFT_C64 && lg > 10) return false;
+        return log2n - lg - tile_log2c_of(lg) >= 1;
+    }
+    int tile_log2c_of(int log2g) const;
     template <typename T> int exec(const Io<T>& io, hipStream_t s);
     template <typename T> int reduce_stats(const T* S, int64_t n_out, int64_t stride, int64_t nb, double* stats, hipStream_t s);
 };
@@ -217,6 +229,8 @@ static int tile_log2c(int dtype, int log2g, int narrow)
 {
     return dtype == MFFT_C64 ? tile_log2c_c64(log2g, narrow) : tile_log2c_c128(log2g, narrow);
 }
+
+int Pow2Engine::tile_log2c_of(int log2g) const { return tile_log2c(dtype, log2g, narrow); }
 
 // How a length above one LDS residency is split into global passes (log2 of each radix, first
 // pass first).  Fewest passes first; within that the radices are balanced, larger ones first.
@@ -421,9 +435,9 @@ void Pow2Engine::release()
             if (q) (void)hipFree(q);
     for (void* q : work)
         if (q) (void)hipFree(q);
-    for (void* q : {stage_in, stage_out})
+    for (void* q : {stage_in, stage_out, r2c_side})
         if (q) (void)hipFree(q);
-    stage_in = stage_out = nullptr;
+    stage_in = stage_out = r2c_side = nullptr;
     d_tw = nullptr; work[0] = work[1] = nullptr; passes.clear();
 }
 
@@ -522,7 +536,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
     // even -- which halves the workspace and keeps one buffer fewer competing for the Infinity
     // Cache.  Not possible when the first pass would overwrite its own input (in-place execution of
     // an odd number of passes) or the output is shorter, strided, segmented or real: two workspaces.
-    bool via_out = np >= 3 && !io.power && io.out_seg == 0 && io.out_stride == n * inner && io.n_out == n &&
+    // (A fused real-input last pass writes 2 n bins or their power: room for the n-element intermediates either way.)
+    bool via_out = np >= 3 && ((!io.power && io.out_seg == 0 && io.out_stride == n * inner && io.n_out == n) || io.r2c) &&
                    !(io.in == io.out && (np & 1)) && !getenv("MFFT_WORK2");
     if (np >= 3 && !via_out && !work[1]) {
         MFFT_HIP(hipMalloc(&work[1], work_bytes));
@@ -595,7 +610,19 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             }
         }
         int rc;
-        if constexpr (sizeof(T) == 4) rc = launch_tile_c64(gp.log2g, mode, a, s);
+        if (last && io.r2c) {
+            if (!r2c_fusable() || io.post || io.stats || io.conj_out || io.out_seg) { set_error("no fused real-input pass for this plan"); return MFFT_E_UNSUPPORTED; }
+            if (!r2c_side) {
+                const size_t sb = (size_t)batch * 2 * (size_t(1) << gp.log2g) * sizeof(cx<T>);
+                MFFT_HIP(hipMalloc(&r2c_side, sb));
+                bytes += (int64_t)sb;
+            }
+            a.side = static_cast<cx<T>*>(r2c_side);
+            a.r2c_power = io.power ? 1 : 0;
+            a.scale = io.scale;
+            if constexpr (sizeof(T) == 4) rc = launch_tile_r2c_c64(gp.log2g, a, s);
+            else rc = launch_tile_r2c_c128(gp.log2g, a, s);
+        } else if constexpr (sizeof(T) == 4) rc = launch_tile_c64(gp.log2g, mode, a, s);
         else rc = launch_tile_c128(gp.log2g, mode, a, s);
         if (rc) return rc;
         src = a.out;
@@ -830,20 +857,26 @@ static int plan_build_parts(Plan* p)
     if (is_pow2(p->n)) {
         p->kind = Plan::POW2;
         // Real input whose HALF-length transform still takes several passes: packed form.  z[j] = x[2j] + i x[2j+1]
-        // is the input buffer itself read as complex, every pass moves half the bytes of the complex route, and one
-        // streaming kernel splits the n/2 bins into the n of the real signal's spectrum.  (Shorter real signals are
-        // read as reals by the single-kernel variants: one pass either way.)
-        // Measured against the promoting route (alternated in one process, 2^24 points per launch): complex128
-        // 0.78-0.89 of its time from 2^15 points on; complex64 0.79-0.86 from 2^20 on, but 0.97-1.12 below (there
-        // the split kernel's extra launch and pass outweigh the halved two-pass transform).
-        const int from = p->dtype == MFFT_C64 ? 20 : 15;
+        // is the input buffer itself read as complex, every pass moves half the bytes of the complex route, and the
+        // last pass splits the n/2 bins into the n of the real signal's spectrum as it stores them
+        // (tile_r2c_kernel.h).  (Shorter real signals are read as reals by the single-kernel variants: one pass
+        // either way.)  Measured against the promoting route (alternated in one process, 2^24 points per launch):
+        // complex128 0.56-0.75 of its time from 2^15 points on, complex64 0.62-0.87 from 2^16 on -- with a separate
+        // split kernel it was 0.78-0.89 and paid only from 2^20 complex64 points.
+        int from = p->dtype == MFFT_C64 ? 16 : 15;
+        if (const char* e = getenv("MFFT_R2C_FROM")) from = atoi(e);        // tuning aid
         if ((p->flags & MFFT_REAL_IN) && !(p->flags & (MFFT_DEMOD | MFFT_INVERSE)) && ilog2(p->n) >= from && (p->n_in & 1) == 0 &&
             !p->lin.batch_stride && !p->lin.seg && !p->lout.batch_stride && !p->lout.seg && !getenv("MFFT_NO_R2C")) {
             p->packed_real = true;
             rc = p->eng.build(p->n / 2, p->batch, p->dtype);
             if (rc) return rc;
-            const size_t half_bytes = (size_t)p->batch * (size_t)(p->n / 2) * 2 * real_size(p->dtype);
-            MFFT_HIP(hipMalloc(&p->d_half, half_bytes));
+            // The split is fused into the last pass wherever that pass has two tiles or more per signal (every length
+            // this route takes); MFFT_R2C_SPLIT_KERNEL=1 keeps the separate kernel and its n/2-element intermediate (A/B)
+            size_t half_bytes = 0;
+            if (!p->eng.r2c_fusable() || getenv("MFFT_R2C_SPLIT_KERNEL")) {
+                half_bytes = (size_t)p->batch * (size_t)(p->n / 2) * 2 * real_size(p->dtype);
+                MFFT_HIP(hipMalloc(&p->d_half, half_bytes));
+            }
             p->workspace += p->eng.bytes + (int64_t)half_bytes;
             p->launches = p->eng.launches() + 1 + ((p->flags & MFFT_STATS) ? 2 : 0);
             return MFFT_OK;
@@ -921,6 +954,15 @@ static int exec_typed(Plan* p, const void* d_in, void* d_out, double scale, doub
         io.win = win; io.win_pairs = win ? 1 : 0;       // the n_in real weights, taken two at a time
         io.n_in = p->n_in / 2; io.n_out = M;
         io.batch = slab;
+        if (!p->d_half) {
+            // the last pass forms the n bins itself (no M-element intermediate, no split kernel)
+            io.out = d_out; io.out_stride = p->n; io.n_out = p->n;
+            io.r2c = true; io.power = power; io.scale = (T)scale;
+            const int rc = p->eng.exec<T>(io, s);
+            if (rc) return rc;
+            if (stats) return p->eng.reduce_stats<T>(static_cast<const T*>(d_out), p->n, p->n, nb, stats, s);
+            return MFFT_OK;
+        }
         int rc = p->eng.exec<T>(io, s);
         if (rc) return rc;
         int64_t blocks = (M + 1 + 255) / 256;

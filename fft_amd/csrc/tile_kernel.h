@@ -126,6 +126,9 @@ template <typename T> struct TArgs {
                           // base: four-column tiles +1..7 % (2^19 x 128 complex64 526 -> 491 us), wider tiles +1.5..3.6 %
                           // (complex64) / 0..1.4 % (complex128) while the plan's data is at most 128 MiB and -4..5 % beyond
     T scale;
+    // fused real-input last pass (tile_r2c_kernel.h): raw outputs of the two self-mirrored columns, 2 G per signal; 1 = |X|^2 out
+    cx<T>* side;
+    int r2c_power;
     // FIRST_HANN: the window 0.5 - 0.5 cos(2 pi i / (n_in - 1)) is evaluated from the turn fraction i * win_inv_m;
     // win_step = ((TX * L) mod (n_in - 1)) / (n_in - 1), the fraction between a thread's consecutive samples
     double win_inv_m, win_step;

@@ -478,6 +478,46 @@ def test_column_plans_on_random_shapes(fa):
     assert not fz.failures, fz.failures[:3]
 
 
+@pytest.mark.parametrize("dtype,split,log2n,batch", [
+    (0, "10,5", 16, 5), (0, "10,6", 17, 3), (0, "9,7", 17, 2), (0, "8,8", 17, 4), (0, "7,9", 17, 3), (0, "6,10", 17, 2),
+    (0, "8,8,4", 21, 1), (0, "8,8,8", 25, 1),
+    (1, "11,4", 16, 3), (1, "10,5", 16, 2), (1, "9,6", 16, 5), (1, "8,7", 16, 2), (1, "7,8", 16, 3), (1, "6,9", 16, 2),
+    (1, "5,10", 16, 4), (1, "4,11", 16, 2), (1, "10,10", 21, 25), (1, "8,8,7", 24, 1)])
+def test_fused_real_input_last_pass_at_every_radix(fa, monkeypatch, dtype, split, log2n, batch):
+    """np.fft.fft of a real signal (final2.py:142-143 with a real f_t) where the split of the half-length transform into
+    the signal's own bins is fused into the last pass: every last-pass radix and tile width of both precisions (the
+    complex128 1024-point tiles in their four- and eight-column forms), one and several signals, complex and power
+    output, against numpy in float64; the route with a separate split kernel gives the same bins."""
+    monkeypatch.setenv("MFFT_SPLIT", split)           # of the half-length plan
+    n = 1 << log2n
+    rdt = np.float32 if dtype == 0 else np.float64
+    tol = TOL[dtype]
+    rng = np.random.default_rng(log2n + 100 * dtype + batch)
+    x = rng.standard_normal((batch, n)).astype(rdt)
+    power = batch >= 25                                # the large case: real output
+    ref = np.fft.fft(x.astype(np.float64), axis=-1)
+    if power:
+        ref = np.abs(ref) ** 2
+    flags = fa.REAL_IN | (fa.POWER if power else 0)
+    with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
+        y = p.exec_host(x)
+    assert rel_l2(y, ref) < tol, rel_l2(y, ref)
+    for b in range(batch):                             # per signal, and the bins of the self-mirrored columns on their own
+        assert rel_l2(y[b], ref[b]) < tol
+    m = n // 2
+    ns = m >> int(split.split(",")[-1])
+    special = np.concatenate([np.arange(0, m + 1, ns), np.arange(ns // 2, m, ns)])
+    special = np.concatenate([special, (n - special[(special > 0) & (special < m)])])
+    assert rel_l2(y[:, special], ref[:, special]) < tol
+    if not power:
+        assert np.array_equal(y[:, 1:m], np.conj(y[:, :m:-1]))
+        monkeypatch.setenv("MFFT_R2C_SPLIT_KERNEL", "1")
+        with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
+            y2 = p.exec_host(x)
+        monkeypatch.delenv("MFFT_R2C_SPLIT_KERNEL")
+        assert rel_l2(y2, ref) < tol and rel_l2(y2, y) < tol
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("log2n", [14, 15, 16, 17, 19, 20, 22])
 def test_real_input_above_one_lds_residency_packed_route(fa, dtype, log2n, monkeypatch):
@@ -492,7 +532,7 @@ def test_real_input_above_one_lds_residency_packed_route(fa, dtype, log2n, monke
     batch = 3 if log2n <= 17 else 1
     x = rng.standard_normal((batch, n)).astype(rdt)
     ref = np.fft.fft(x.astype(np.float64), axis=-1)
-    packed = log2n >= (20 if dtype == 0 else 15)
+    packed = log2n >= (16 if dtype == 0 else 15)
     with fa.Plan(n, batch=batch, dtype=dtype, flags=fa.REAL_IN) as p:
         y = p.exec_host(x, scale=0.5)
         launches = p.launches

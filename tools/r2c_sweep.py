@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Real-input transforms above one LDS residency: the packed route (n/2 complex samples + split kernel) against
-the route that promotes the reals to complex (MFFT_NO_R2C=1, read when the plan is built) and against the complex
-transform of the same length, alternated in one process on device buffers.
+"""Real-input transforms above one LDS residency: the packed route (n/2 complex samples, the split into the n bins fused
+into the last pass) against the same route with a separate split kernel (MFFT_R2C_SPLIT_KERNEL=1), against the route
+that promotes the reals to complex (MFFT_NO_R2C=1; both read when the plan is built) and against the complex transform
+of the same length, alternated in one process on device buffers.
     python tools/r2c_sweep.py [--dtype 1] [--log2n 15 16 ... 24] [--flags 0]      (flags: 3 = Hann + power)"""
 import argparse
 import os
@@ -34,6 +35,9 @@ def main():
         plans = {}
         os.environ.pop("MFFT_NO_R2C", None)
         plans["packed"] = (fft_amd.Plan(n, batch=batch, dtype=args.dtype, flags=args.flags | fft_amd.REAL_IN), xr)
+        os.environ["MFFT_R2C_SPLIT_KERNEL"] = "1"
+        plans["split"] = (fft_amd.Plan(n, batch=batch, dtype=args.dtype, flags=args.flags | fft_amd.REAL_IN), xr)
+        os.environ.pop("MFFT_R2C_SPLIT_KERNEL")
         os.environ["MFFT_NO_R2C"] = "1"
         plans["promoted"] = (fft_amd.Plan(n, batch=batch, dtype=args.dtype, flags=args.flags | fft_amd.REAL_IN), xr)
         os.environ.pop("MFFT_NO_R2C")
@@ -50,7 +54,7 @@ def main():
                 times[k].append(e0.elapsed_time(e1) / 5 * 1e3)
         med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         print(f"2^{lg} x {batch} {'complex64' if args.dtype == 0 else 'complex128'} flags {args.flags}: real input packed "
-              f"{med['packed']:9.1f} us (launches {plans['packed'][0].launches}) | promoted {med['promoted']:9.1f} us "
+              f"{med['packed']:9.1f} us (launches {plans['packed'][0].launches}) | separate split kernel {med['split']:9.1f} us | promoted {med['promoted']:9.1f} us "
               f"(launches {plans['promoted'][0].launches}) | complex input {med['complex']:9.1f} us   packed/promoted "
               f"{med['packed'] / med['promoted']:.2f}  packed/complex {med['packed'] / med['complex']:.2f}", flush=True)
         for p, _ in plans.values():
