@@ -213,10 +213,10 @@ int launch_tile_r2c_one(const TArgs<T>& a, hipStream_t s)
     if (a.log2_tiles < 1 || a.side == nullptr || a.log2_w != 0) { set_error("fused real-input pass needs at least two tiles per signal"); return MFFT_E_INVALID; }
     const int64_t total = a.batch << (a.log2_tiles - 1);
     if (total <= 0) return MFFT_OK;
+    if (a.batch > 65535) { set_error("at most 65535 real signals per call above one LDS residency"); return MFFT_E_UNSUPPORTED; }
     hipLaunchKernelGGL(kern, dim3(pick_grid(per_cu, total)), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     const int G = 1 << LOG2G;
-    if (a.batch > 65535) { set_error("at most 65535 real signals per call above one LDS residency"); return MFFT_E_UNSUPPORTED; }
     const dim3 grid((unsigned)((2 * G + 1 + 255) / 256), (unsigned)a.batch);
     const int log2n = a.log2_ns + LOG2G + 1;
     if (a.r2c_power)
