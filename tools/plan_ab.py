@@ -42,7 +42,11 @@ def main():
     ap.add_argument("--values", nargs="+", required=True)
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--inner-reps", type=int, default=0, help="executions per timed bracket (0: by size)")
+    ap.add_argument("--lib", default="", help="A/B build of the library to load (make VARIANT=<tag>: fft_amd/lib/libmfft_<tag>.so)")
     args = ap.parse_args()
+    if args.lib:
+        from fft_amd import _lib
+        _lib.LIB_PATH = os.path.join(ROOT, "fft_amd", "lib", f"libmfft_{args.lib}.so")
     torch.cuda.set_device(0)
     n = 1 << args.log2n
     n_in = args.n_in or n
