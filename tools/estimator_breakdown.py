@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where one fft_from_timeseries call spends its time: the Python prologue (validation, staging), the C call
 (mfft_lines_host: upload, transform, peak pipeline, normal equations, downloads), and the Python tail (axis, weights,
-pruning, sorting).  python tools/estimator_breakdown.py [--n0 8001 --pad 32]"""
+pruning, sorting); then fft_extract_E_p and two of its four device round trips.
+    python tools/estimator_breakdown.py [--n0 8001 --pad 32]"""
 import argparse
 import os
 import sys
@@ -68,6 +69,21 @@ def main():
     print(f"N0={args.n0} Nfft={args.n0 * args.pad}: fft_from_timeseries median {med(tot):.0f} us")
     for k, v in spans.items():
         print(f"    {k:40s} {med(v):7.0f} us")
+    # the combined app's estimator (streamlit_app_combined.py:190-251) and its device round trips
+    H = np.array([[0.3, 1.0, 0.0], [1.0, -0.2, 0.7], [0.0, 0.7, 0.5]])
+
+    def timed(fn):
+        v = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            fn()
+            v.append(time.perf_counter() - t0)
+        return med(v)
+    f3 = sp.return_amplitude(H, 0, times)
+    print(f"N0={args.n0} pad={args.pad}: fft_extract_E_p median {timed(lambda: sp.fft_extract_E_p(H, 0, times, pad=args.pad)):.0f} us")
+    print(f"    {'return_amplitude (generator + download)':40s} {timed(lambda: sp.return_amplitude(H, 0, times)):7.0f} us")
+    print(f"    {'rough pass (statistics only)':40s} "
+          f"{timed(lambda: sp.power_spectrum(f3, args.pad * args.n0, 0.01, use_hann=True, want_spectrum=False)):7.0f} us")
 
 
 if __name__ == "__main__":
