@@ -148,6 +148,62 @@ def test_first_pass_with_evaluated_window_and_range_checked_loads(fa, monkeypatc
             assert rel_l2(yt, ref) < tol if np.any(ref) else not np.any(yt)
 
 
+@pytest.mark.parametrize("var,value,case", [
+    ("MFFT_FOUR_PASSES", "1", "c128_2p20"), ("MFFT_GENERAL_PROLOGUE", "1", "padded_window"), ("MFFT_GENERAL_PROLOGUE", "1", "chirpz"),
+    ("MFFT_NO_NARROW_RADIX", "1", "c64_2p19"), ("MFFT_TILE_BUF", "0", "c64_2p19"), ("MFFT_TILE_BUF", "4", "c64_2p20"),
+    ("MFFT_TILE_BUF", "12", "c128_2p20"), ("MFFT_TILE_NT", "0", "c64_2p20"), ("MFFT_TILE_NT", "3", "c128_2p20"),
+    ("MFFT_TILE_NT_PASS", "1,3,2", "c64_2p20"), ("MFFT_WORK2", "1", "c64_2p20"), ("MFFT_R2C_FROM", "30", "real_2p17"),
+    ("MFFT_BALANCED_COLUMNS", "1", "columns"), ("MFFT_NARROW_COLUMNS", "1", "columns"),
+    ("MFFT_COPY_THREADS", "1", "host_path"), ("MFFT_COPY_STREAM", "0", "host_path")])
+def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, case):
+    """Every variable the library reads when a plan is built or executed (tuning aids: pass splits, cache policies,
+    access forms, routes) selects another way to the same bins: np.fft.fft (final2.py:143) stays the reference."""
+    from fft_amd.engine import ColumnPlan
+    monkeypatch.setenv(var, value)
+    rng = np.random.default_rng(len(var) + len(case))
+
+    def cplx(shape, cdt):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(cdt)
+    if case in ("c64_2p19", "c64_2p20", "c128_2p20"):
+        dtype = 0 if case.startswith("c64") else 1
+        n = 1 << int(case[-2:])
+        x = cplx((2, n), np.complex64 if dtype == 0 else np.complex128)
+        with fa.Plan(n, batch=2, dtype=dtype) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y, np.fft.fft(x.astype(np.complex128), axis=-1)) < TOL[dtype]
+    elif case == "padded_window":
+        n, n_in = 1 << 17, 100001
+        x = cplx((3, n_in), np.complex64)
+        with fa.Plan(n, n_in=n_in, batch=3, dtype=0, flags=fa.HANN) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y, np.fft.fft(x.astype(np.complex128) * np.hanning(n_in), n, axis=-1)) < TOL[0]
+    elif case == "chirpz":
+        n, n_in = 24016, 1501
+        x = cplx((2, n_in), np.complex128)
+        with fa.Plan(n, n_in=n_in, batch=2, dtype=1, flags=fa.HANN) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y, np.fft.fft(x * np.hanning(n_in), n, axis=-1)) < TOL[1]
+    elif case == "real_2p17":
+        n = 1 << 17
+        x = rng.standard_normal((2, n))
+        with fa.Plan(n, batch=2, dtype=1, flags=fa.REAL_IN) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y, np.fft.fft(x, axis=-1)) < TOL[1]
+    elif case == "columns":
+        n, inner = 4096, 256
+        x = cplx((n, inner), np.complex64)
+        with ColumnPlan(n, inner, dtype=0) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y, np.fft.fft(x.astype(np.complex128), axis=0)) < TOL[0]
+    else:                                   # the pipelined host path (pinned staging, copy threads)
+        n = 4096
+        x = cplx((6000, n), np.complex64)
+        with fa.Plan(n, batch=6000, dtype=0, flags=fa.POWER) as p:
+            y = p.exec_host(x)
+        assert rel_l2(y[:50], np.abs(np.fft.fft(x[:50].astype(np.complex128), axis=-1)) ** 2) < TOL[0]
+        assert rel_l2(y[-50:], np.abs(np.fft.fft(x[-50:].astype(np.complex128), axis=-1)) ** 2) < TOL[0]
+
+
 def test_large_complex64_plans_on_sampled_bins(fa):
     """2^26 and 2^27 complex64 points (9,9,8 and 9,9,9: one and two twiddled 512-point passes): sampled bins
     against the DFT evaluated directly in float64, and Parseval."""
