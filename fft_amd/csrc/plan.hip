@@ -94,6 +94,24 @@ int device_cu_count()
     return cached;
 }
 
+// Is `s` recording into a graph (hipStreamBeginCapture by the caller, torch.cuda.graph)?  Nothing may be
+// allocated then, and events recorded outside the capture may not be waited for.
+static bool stream_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+static int first_use_alloc(void** ptr, size_t bytes, hipStream_t s)
+{
+    if (stream_capturing(s)) {
+        set_error("this execution needs a buffer the plan allocates on first use: run it once outside stream capture first");
+        return MFFT_E_UNSUPPORTED;
+    }
+    MFFT_HIP(hipMalloc(ptr, bytes));
+    return MFFT_OK;
+}
+
 int blocks_per_cu(const void* kernel, int block, size_t lds)
 {
     int per_cu = 0;
@@ -514,13 +532,13 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             return MFFT_OK;
         };
         if (stage_i) {
-            if (!stage_in) MFFT_HIP(hipMalloc(&stage_in, (size_t)batch * (size_t)io.n_in * in_esz));
+            if (!stage_in) { const int ra = first_use_alloc(&stage_in, (size_t)batch * (size_t)io.n_in * in_esz, s); if (ra) return ra; }
             const int rc = seg_copy(io.in, stage_in, in_esz, io.n_in, io.in_stride, io.in_seg, io.in_seg_stride, 1);
             if (rc) return rc;
             a.in = stage_in; a.in_stride = io.n_in; a.in_seg = a.in_seg_stride = 0;
         }
         if (stage_o) {
-            if (!stage_out) MFFT_HIP(hipMalloc(&stage_out, (size_t)batch * (size_t)io.n_out * out_esz));
+            if (!stage_out) { const int ra = first_use_alloc(&stage_out, (size_t)batch * (size_t)io.n_out * out_esz, s); if (ra) return ra; }
             a.out = stage_out; a.out_stride = io.n_out; a.out_seg = a.out_seg_stride = 0;
         }
         int rc;
@@ -540,7 +558,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
     bool via_out = np >= 3 && ((!io.power && io.out_seg == 0 && io.out_stride == n * inner && io.n_out == n) || io.r2c) &&
                    !(io.in == io.out && (np & 1)) && !getenv("MFFT_WORK2");
     if (np >= 3 && !via_out && !work[1]) {
-        MFFT_HIP(hipMalloc(&work[1], work_bytes));
+        const int ra = first_use_alloc(&work[1], work_bytes, s);
+        if (ra) return ra;
         bytes += (int64_t)work_bytes;
     }
     // statistics of dense power spectra: a reduction of their own after the last pass (no atomics)
@@ -614,7 +633,8 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             if (!r2c_fusable() || io.post || io.stats || io.conj_out || io.out_seg) { set_error("no fused real-input pass for this plan"); return MFFT_E_UNSUPPORTED; }
             if (!r2c_side) {
                 const size_t sb = (size_t)batch * 2 * (size_t(1) << gp.log2g) * sizeof(cx<T>);
-                MFFT_HIP(hipMalloc(&r2c_side, sb));
+                const int ra = first_use_alloc(&r2c_side, sb, s);
+                if (ra) return ra;
                 bytes += (int64_t)sb;
             }
             a.side = static_cast<cx<T>*>(r2c_side);
@@ -1043,6 +1063,11 @@ static int plan_exec_ordered(Plan* p, const void* d_in, void* d_out, double scal
 {
     if (!p->shares_state) return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
     std::lock_guard<std::mutex> order(p->order_mu);
+    if (stream_capturing(s)) {
+        // recorded into the caller's graph: the graph orders it; the caller orders launches of that graph against
+        // other executions of this plan (events from outside a capture cannot be waited for inside it)
+        return plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);
+    }
     if (!p->last_done) MFFT_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     if (p->have_last && p->last_stream != s) MFFT_HIP(hipStreamWaitEvent(s, p->last_done, 0));
     const int rc = plan_exec(p, d_in, d_out, scale, mu, t0, dt, d_stats, s, slab, tables);

@@ -133,7 +133,12 @@ int mfft_plan_launches(mfft_plan plan, int* launches);
  * bins).  mu, t0, dt are read only with MFFT_DEMOD.  stream: a hipStream_t, or
  * NULL for the default stream.  The call is asynchronous.  d_out may be d_in for
  * a dense complex -> complex transform of full-length input (n_in == n, no
- * MFFT_REAL_IN, no MFFT_POWER); any other aliasing of the two is undefined. */
+ * MFFT_REAL_IN, no MFFT_POWER); any other aliasing of the two is undefined.
+ * Stream capture: when `stream` is recording into a graph (hipStreamBeginCapture, torch.cuda.graph) the
+ * plan's kernels are recorded like any others -- nothing is allocated and no event from outside the capture
+ * is waited for; a plan that allocates a buffer on first use (a second pass workspace, staging copies)
+ * returns MFFT_E_UNSUPPORTED until it has been executed once outside a capture.  Replays of such a graph are
+ * ordered against other executions of the same plan by the caller, not by the library. */
 int mfft_exec(mfft_plan plan, const void* d_in, void* d_out, double scale,
               double mu, double t0, double dt, double* d_stats, void* stream);
 
