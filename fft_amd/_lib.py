@@ -64,6 +64,8 @@ SIGNATURES = {
     "mfft_return_amplitude": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int, _dbl, _vp]),
     "mfft_normalize_by_max": (_int, [_vp, _vp, _i64, _vp, _int, _vp]),
     "mfft_transpose": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "mfft_host_alloc": (_int, [ctypes.POINTER(_vp), _i64]),
+    "mfft_host_free": (_int, [_vp]),
     "mfft_swap_axes": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "mfft_swap_axes_strided": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "mfft_twiddle_tile": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),

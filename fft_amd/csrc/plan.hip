@@ -1686,6 +1686,14 @@ int mfft_exec_host_peaks(mfft_plan plan, const void* h_in, void* h_out, double s
 
 static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// Is this host pointer page-locked memory the device can write directly (mfft_host_alloc, hipHostMalloc)?
+static bool host_pinned(const void* h)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, h) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 // The samples of a line search: handed over by the caller (h_x), or generated on the device from the
 // eigen-data of `nblocks` small Hermitian blocks (the batch's return amplitudes f(t), final2.py:85-97).
 struct LineSource {
@@ -1802,8 +1810,10 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
     // (a download into a fresh pageable array runs at ~17 GB/s, one staging thread, page faults
     // included; from 1 MiB on the copy threads move them out of the pinned buffer ~2x faster).
     // Below 1 MiB the direct download is faster than the cross-stream hand-off (24016 bins: 0.18 against 0.22 ms per call).
-    bool side = h_S != nullptr && out_bytes >= (size_t(1) << 20) && out_bytes <= (size_t(256) << 20);
-    if (side && !p->h_spec && hipHostMalloc((void**)&p->h_spec, out_bytes, hipHostMallocDefault) != hipSuccess) { p->h_spec = nullptr; side = false; }
+    // A caller's page-locked array (mfft_host_alloc) takes the download itself: no staging buffer, no second copy.
+    const bool direct = h_S != nullptr && host_pinned(h_S);
+    bool side = h_S != nullptr && out_bytes >= (size_t(1) << 20) && (direct || out_bytes <= (size_t(256) << 20));
+    if (side && !direct && !p->h_spec && hipHostMalloc((void**)&p->h_spec, out_bytes, hipHostMallocDefault) != hipSuccess) { p->h_spec = nullptr; side = false; }
     if (side && !p->s_spec && hipStreamCreateWithFlags(&p->s_spec, hipStreamNonBlocking) != hipSuccess) { p->s_spec = nullptr; side = false; }
     if (side && !p->ev_spec && hipEventCreateWithFlags(&p->ev_spec, hipEventDisableTiming) != hipSuccess) { p->ev_spec = nullptr; side = false; }
     if (side && normalize && !p->d_norm && hipMalloc(&p->d_norm, out_bytes) != hipSuccess) { p->d_norm = nullptr; side = false; }
@@ -1826,7 +1836,7 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
         MFFT_HIP(hipEventRecord(p->ev_spec, sm));
         MFFT_HIP(hipStreamWaitEvent(p->s_spec, p->ev_spec, 0));
         if (normalize) { rc = normalise(p->d_norm, p->s_spec); if (rc) return rc; }
-        MFFT_HIP(hipMemcpyAsync(p->h_spec, normalize ? p->d_norm : p->d_out, out_bytes, hipMemcpyDeviceToHost, p->s_spec));
+        MFFT_HIP(hipMemcpyAsync(direct ? h_S : p->h_spec, normalize ? p->d_norm : p->d_out, out_bytes, hipMemcpyDeviceToHost, p->s_spec));
     }
     PeakArgs a;
     a.n = n; a.cap = cap;
@@ -1884,12 +1894,12 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
         MFFT_HIP(hipMemcpyAsync(h_S, p->d_out, out_bytes, hipMemcpyDeviceToHost, sm));
     }
     uint64_t ticket = 0;
-    const bool pooled = side;
+    const bool pooled = side && !direct;
     if (side) {
         const hipError_t e_side = hipStreamSynchronize(p->s_spec);
         side_sync.armed = false;
         if (e_side != hipSuccess) return hip_fail(e_side, "spectrum download", __FILE__, __LINE__);
-        ticket = CopyPool::out().start(h_S, p->h_spec, out_bytes);
+        if (pooled) ticket = CopyPool::out().start(h_S, p->h_spec, out_bytes);
     }
     const hipError_t e_main = hipStreamSynchronize(sm);
     main_sync.armed = false;
@@ -1947,6 +1957,21 @@ int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const do
                            static_cast<const double*>(d_in), static_cast<double*>(d_out), count, d_max, (int64_t)0);
     else { set_error("bad dtype"); return MFFT_E_INVALID; }
     MFFT_HIP(hipGetLastError());
+    return MFFT_OK;
+}
+
+int mfft_host_alloc(void** out, int64_t bytes)
+{
+    if (!out || bytes < 1) { set_error("bad argument"); return MFFT_E_INVALID; }
+    *out = nullptr;
+    MFFT_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return MFFT_OK;
+}
+
+int mfft_host_free(void* p)
+{
+    if (!p) return MFFT_OK;
+    MFFT_HIP(hipHostFree(p));
     return MFFT_OK;
 }
 

@@ -13,6 +13,7 @@ import threading
 import numpy as np
 
 from . import _lib
+from . import hostmem
 
 
 def _addr(buf) -> int:
@@ -175,7 +176,7 @@ class Plan:
         want = int(want)
         prm = _lib.PeakParams(float(axis_dt), float(dc_guard), float(guard), int(bool(include_dc)), int(mode), want)
         B = self.batch
-        S = np.empty((B, self.n), dtype=self.out_dtype) if want_spectrum else None
+        S = hostmem.empty((B, self.n), self.out_dtype) if want_spectrum else None
         stats = np.zeros((B, 3), dtype=np.float64)
         idx = np.empty((B, max(want, 1)), dtype=np.int64)
         om = np.empty((B, max(want, 1)), dtype=np.float64)
@@ -214,7 +215,7 @@ class Plan:
             raise ValueError("`times` must have one entry per sample")
         want = int(want)
         prm = _lib.PeakParams(float(axis_dt), float(dc_guard), float(guard), int(bool(include_dc)), int(mode), want)
-        S = np.empty((B, self.n), dtype=self.out_dtype) if want_spectrum else None
+        S = hostmem.empty((B, self.n), self.out_dtype) if want_spectrum else None
         stats = np.zeros((B, 3), dtype=np.float64)
         idx = np.empty((B, max(want, 1)), dtype=np.int64)
         om = np.empty((B, max(want, 1)), dtype=np.float64)

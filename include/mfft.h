@@ -277,6 +277,13 @@ int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const do
 
 /* out[b][c][r] = in[b][r][c]  for `batch` matrices of rows x cols complex elements
  * (local re-layout step of the pencil / four-step decompositions). */
+/* Page-locked host memory the device reads and writes directly.  No counterpart in the reference (its arrays are
+ * numpy's): the host layer hands the spectra of fft_from_timeseries / fft_extract_E_p (final2.py:146, 188) back in
+ * such blocks, so that mfft_lines_host downloads them in place instead of into a staging buffer and copying again.
+ * Any host pointer works everywhere; a pinned one is merely faster. */
+int mfft_host_alloc(void** out, int64_t bytes);
+int mfft_host_free(void* p);
+
 int mfft_transpose(const void* d_in, void* d_out, int64_t rows, int64_t cols, int64_t batch,
                    int dtype, void* stream);
 

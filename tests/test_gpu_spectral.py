@@ -645,3 +645,35 @@ def test_fft_signature_corners_and_random_shapes(fa):
     del fz.failures[:]
     assert fz.run(501, 503, 50, verbose=False) >= 150
     assert not fz.failures, fz.failures[:3]
+
+
+def test_spectra_come_back_in_recycled_page_locked_arrays():
+    """The spectrum fft_from_timeseries returns (final2.py:146, 188) lives in a page-locked block the device wrote
+    directly; the block is recycled once the last view of it is gone, and never while one is alive."""
+    import gc
+    from fft_amd import hostmem, spectral as sp
+    times = np.arange(8001) * 0.01
+    f1 = np.exp(-1j * 1.3 * times) + 0.5 * np.exp(1j * 0.4 * times)
+    f2 = np.exp(-1j * 2.1 * times)
+    hostmem.release_free_blocks()
+    E1, p1, ax1, S1 = sp.fft_from_timeseries(f1, times, n_levels=2, pad_factor=32)
+    ref1 = so.fft_from_timeseries(f1, times, n_levels=2, pad_factor=32)
+    assert np.allclose(E1, ref1[0], atol=1e-9) and rel_l2(S1, ref1[3]) < 1e-12
+    keep = S1[1000:1010]                      # a view keeps the block out of the pool
+    addr1 = S1.ctypes.data
+    E2, p2, ax2, S2 = sp.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)
+    assert S2.ctypes.data != addr1
+    assert rel_l2(S1, ref1[3]) < 1e-12        # untouched by the second call
+    assert rel_l2(S2, so.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)[3]) < 1e-12
+    snapshot = keep.copy()
+    del S1, E1, p1, ax1
+    gc.collect()
+    S3 = sp.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)[3]
+    assert S3.ctypes.data != addr1 and np.array_equal(keep, snapshot)
+    del keep
+    gc.collect()
+    addrs = {sp.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)[3].ctypes.data for _ in range(6)}
+    assert addr1 in addrs                     # recycled now
+    S4 = sp.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)[3]
+    S4[:10] = 7.0                             # writable like any numpy array
+    assert S4.flags.writeable and S4.dtype == np.float64 and S4.shape == (256032,)
