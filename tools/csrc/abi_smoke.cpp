@@ -157,6 +157,106 @@ int main()
         int64_t fr = 0, tot = 0;
         REQUIRE(mfft_device_memory(&fr, &tot) == MFFT_OK && fr > 0 && fr <= tot);
     }
+    // ---- device-buffer executions: multi-pass, windowed + zero-padded tiles, packed real input, recorded into a graph ---
+    {
+        struct Case { int64_t n, n_in, batch; int dtype; uint32_t flags; };
+        const Case cases[] = {{1 << 20, 1 << 20, 2, MFFT_C128, 0}, {1 << 17, 100001, 3, MFFT_C64, MFFT_HANN},
+                              {1 << 18, 1 << 18, 2, MFFT_C128, MFFT_REAL_IN}, {1 << 17, (1 << 17) - 2, 2, MFFT_C64, MFFT_REAL_IN | MFFT_HANN | MFFT_POWER | MFFT_STATS},
+                              {24016, 1501, 2, MFFT_C128, MFFT_HANN | MFFT_POWER | MFFT_STATS}, {1 << 22, 1 << 22, 1, MFFT_C64, MFFT_POWER}};
+        hipStream_t st = nullptr;
+        REQUIRE(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+        for (const Case& c : cases) {
+            const size_t rs = c.dtype == MFFT_C64 ? 4 : 8;
+            const size_t in_bytes = (size_t)(c.batch * c.n_in) * rs * ((c.flags & MFFT_REAL_IN) ? 1 : 2);
+            const size_t out_bytes = (size_t)(c.batch * c.n) * rs * ((c.flags & MFFT_POWER) ? 1 : 2);
+            void *d_in = nullptr, *d_out = nullptr, *d_stats = nullptr;
+            REQUIRE(hipMalloc(&d_in, in_bytes) == hipSuccess && hipMalloc(&d_out, out_bytes) == hipSuccess && hipMalloc(&d_stats, 24 * (size_t)c.batch) == hipSuccess);
+            REQUIRE(hipMemset(d_in, 0, in_bytes) == hipSuccess);
+            mfft_plan plan = nullptr;
+            REQUIRE(mfft_plan_1d(&plan, c.n, c.n_in, c.batch, c.dtype, c.flags) == MFFT_OK);
+            double* stats = (c.flags & MFFT_STATS) ? (double*)d_stats : nullptr;
+            for (int rep = 0; rep < 2; ++rep) REQUIRE(mfft_exec(plan, d_in, d_out, 0.5, 0.0, 0.0, 1.0, stats, st) == MFFT_OK);
+            REQUIRE(hipStreamSynchronize(st) == hipSuccess);
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t gexec = nullptr;
+            REQUIRE(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess);
+            const int rc = mfft_exec(plan, d_in, d_out, 0.5, 0.0, 0.0, 1.0, stats, st);
+            REQUIRE(hipStreamEndCapture(st, &graph) == hipSuccess);
+            REQUIRE(rc == MFFT_OK && graph != nullptr);
+            REQUIRE(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess);
+            for (int rep = 0; rep < 2; ++rep) REQUIRE(hipGraphLaunch(gexec, st) == hipSuccess);
+            REQUIRE(hipStreamSynchronize(st) == hipSuccess);
+            (void)hipGraphExecDestroy(gexec); (void)hipGraphDestroy(graph);
+            REQUIRE(mfft_plan_destroy(plan) == MFFT_OK);
+            (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_stats);
+        }
+        (void)hipStreamDestroy(st);
+    }
+    // ---- layouts, block copies, column groups, device-side helpers ---------------------------------------------------
+    {
+        const int64_t n = 4096, rows = 8, seg = 512;
+        mfft_layout lin{0, 0, 0}, lout{rows * seg, seg, rows * seg};          // bins of row b land at [k / seg][b][k % seg]
+        lout.batch_stride = seg;
+        mfft_plan plan = nullptr;
+        REQUIRE(mfft_plan_1d_layout(&plan, n, n, rows, MFFT_C64, 0, &lin, &lout) == MFFT_OK);
+        void *d_a = nullptr, *d_b = nullptr, *d_cnt = nullptr, *d_idx = nullptr, *d_max = nullptr;
+        const size_t bytes = (size_t)(rows * n) * 8;
+        REQUIRE(hipMalloc(&d_a, bytes) == hipSuccess && hipMalloc(&d_b, bytes) == hipSuccess && hipMalloc(&d_cnt, 8) == hipSuccess &&
+                hipMalloc(&d_idx, 8 * 1024) == hipSuccess && hipMalloc(&d_max, 8) == hipSuccess);
+        REQUIRE(hipMemset(d_a, 0, bytes) == hipSuccess && hipMemset(d_cnt, 0, 8) == hipSuccess);
+        REQUIRE(mfft_exec(plan, d_a, d_b, 1.0, 0.0, 0.0, 1.0, nullptr, nullptr) == MFFT_OK);
+        REQUIRE(mfft_plan_destroy(plan) == MFFT_OK);
+        REQUIRE(mfft_swap_axes(d_a, d_b, 8, 8, n / 8, MFFT_C64, nullptr) == MFFT_OK);
+        REQUIRE(mfft_swap_axes_strided(d_a, d_b, 4, 8, 128, n, 128, MFFT_C64, nullptr) == MFFT_OK);
+        REQUIRE(mfft_transpose(d_a, d_b, rows, n, 1, MFFT_C64, nullptr) == MFFT_OK);
+        REQUIRE(mfft_twiddle_tile(d_a, rows, n, 3, 5, rows * n * 4, MFFT_C64, nullptr) == MFFT_OK);
+        REQUIRE(mfft_local_maxima(d_a, 2 * rows * n, MFFT_C64, (int64_t*)d_idx, 1024, (int64_t*)d_cnt, nullptr) == MFFT_OK);
+        const double one = 2.0;
+        REQUIRE(hipMemcpy(d_max, &one, 8, hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(mfft_normalize_by_max(d_a, d_b, 2 * rows * n, (const double*)d_max, MFFT_C64, nullptr) == MFFT_OK);
+        mfft_plan cols = nullptr;                                              // a column group written into a wider array
+        REQUIRE(mfft_plan_1d_columns_ld(&cols, 256, 64, 1, MFFT_C64, 0, 0, 128) == MFFT_OK);
+        REQUIRE(mfft_exec(cols, d_a, d_b, 1.0, 0.0, 0.0, 1.0, nullptr, nullptr) == MFFT_OK);
+        REQUIRE(mfft_plan_destroy(cols) == MFFT_OK);
+        const double w[2] = {0.5, -1.5}, c0[4] = {0.6, 0.0, 0.8, 0.0}, vrow[4] = {0.6, 0.0, 0.8, 0.0};
+        REQUIRE(mfft_return_amplitude(d_b, 1000, 0.0, 0.01, w, c0, vrow, 2, 1.0, nullptr) == MFFT_OK);
+        REQUIRE(hipDeviceSynchronize() == hipSuccess);
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_cnt); (void)hipFree(d_idx); (void)hipFree(d_max);
+    }
+    // ---- the block pipeline (samples generated on the device) into a page-locked spectrum ------------------------------
+    {
+        const int64_t n0 = 4001, n = 32 * n0, batch = 3;
+        const int nk = 3, want = 3;
+        const double dt = 0.01;
+        mfft_plan plan = nullptr;
+        REQUIRE(mfft_plan_1d(&plan, n, n0, batch, MFFT_C128, MFFT_HANN | MFFT_POWER | MFFT_STATS) == MFFT_OK);
+        std::vector<double> t((size_t)n0), w((size_t)(batch * nk)), c0((size_t)(2 * batch * nk), 0.0), vrow((size_t)(2 * batch * nk), 0.0);
+        for (int64_t j = 0; j < n0; ++j) t[(size_t)j] = dt * (double)j;
+        for (int64_t b = 0; b < batch; ++b)
+            for (int k = 0; k < nk; ++k) {
+                w[(size_t)(b * nk + k)] = -2.0 + 1.7 * k + 0.1 * (double)b;
+                c0[(size_t)(2 * (b * nk + k))] = vrow[(size_t)(2 * (b * nk + k))] = std::sqrt((k + 1) / 6.0);
+            }
+        const double domega = 2 * M_PI / (t.back() - t.front());
+        mfft_peak_params prm{dt, 1.5 * domega, 1.2 * domega, 0, 0, want};
+        void* S = nullptr;
+        REQUIRE(mfft_host_alloc(&S, (int64_t)(batch * n) * 8) == MFFT_OK && S != nullptr);
+        std::vector<double> S2((size_t)(batch * n)), stats(3 * batch), om((size_t)(batch * want)), hgt((size_t)(batch * want)),
+            gram((size_t)batch * (2 * want * want + 2 * want + 1));
+        std::vector<int64_t> idx((size_t)(batch * want));
+        std::vector<int32_t> cnt((size_t)batch);
+        REQUIRE(mfft_lines_blocks_host(plan, w.data(), c0.data(), vrow.data(), nk, 1.0, dt, t.data(), &prm, 1, S, stats.data(), idx.data(),
+                                       om.data(), hgt.data(), cnt.data(), gram.data()) == MFFT_OK);
+        REQUIRE(mfft_lines_blocks_host(plan, w.data(), c0.data(), vrow.data(), nk, 1.0, dt, t.data(), &prm, 1, S2.data(), stats.data(), idx.data(),
+                                       om.data(), hgt.data(), cnt.data(), gram.data()) == MFFT_OK);
+        for (int64_t b = 0; b < batch; ++b) REQUIRE(cnt[(size_t)b] == want);
+        double worst = 0.0;
+        for (size_t i = 0; i < S2.size(); ++i) worst = std::fmax(worst, std::fabs(S2[i] - static_cast<const double*>(S)[i]));
+        REQUIRE(worst == 0.0);                                                  // the page-locked and the pageable destination agree
+        REQUIRE(mfft_host_free(S) == MFFT_OK && mfft_host_free(nullptr) == MFFT_OK);
+        REQUIRE(mfft_host_alloc(nullptr, 8) == MFFT_E_INVALID);
+        REQUIRE(mfft_plan_destroy(plan) == MFFT_OK);
+    }
     // ---- distributed plans: four ranks sharing the device, a host thread each -----------------------------------
     {
         const int P = 4;
@@ -175,6 +275,9 @@ int main()
                 int rc = hipMalloc(&d_in, (size_t)local * 8) == hipSuccess && hipMalloc(&d_out, (size_t)local * 8) == hipSuccess ? 0 : -99;
                 if (!rc) rc = hipMemcpy(d_in, mine.data(), (size_t)local * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -98;
                 if (!rc) rc = mfft_plan_2d_dist(&p2, comms[r], n0, n1, MFFT_C64, 1, 0, 0);
+                int chunks = 0, groups = 0; int64_t ws = 0;
+                if (!rc) rc = mfft_dist_plan_info(p2, &chunks, &groups, &ws);
+                if (!rc && (chunks < 1 || groups < 1 || ws <= 0)) rc = -95;
                 if (!rc) rc = mfft_dist_exec(p2, d_in, d_out, nullptr);
                 if (!rc) rc = mfft_plan_1d_dist(&p1, comms[r], n0, n1, MFFT_C64, 1, 2, 0);
                 if (!rc) rc = mfft_dist_exec(p1, d_in, d_out, nullptr);       // result overwritten below: exercised for its host side
