@@ -562,6 +562,16 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         if (ra) return ra;
         bytes += (int64_t)work_bytes;
     }
+    if (io.r2c) {
+        // the fused real-input last pass: checked, and its side buffer taken, before anything is enqueued
+        if (!r2c_fusable() || io.post || io.stats || io.conj_out || io.out_seg) { set_error("no fused real-input pass for this plan"); return MFFT_E_UNSUPPORTED; }
+        if (!r2c_side) {
+            const size_t sb = (size_t)batch * 2 * (size_t(1) << passes.back().log2g) * sizeof(cx<T>);
+            const int ra = first_use_alloc(&r2c_side, sb, s);
+            if (ra) return ra;
+            bytes += (int64_t)sb;
+        }
+    }
     // statistics of dense power spectra: a reduction of their own after the last pass (no atomics)
     const bool stats_after = io.stats && io.power && io.out_seg == 0 && work[0] != nullptr;
     const void* src = io.in;
@@ -630,13 +640,6 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         }
         int rc;
         if (last && io.r2c) {
-            if (!r2c_fusable() || io.post || io.stats || io.conj_out || io.out_seg) { set_error("no fused real-input pass for this plan"); return MFFT_E_UNSUPPORTED; }
-            if (!r2c_side) {
-                const size_t sb = (size_t)batch * 2 * (size_t(1) << gp.log2g) * sizeof(cx<T>);
-                const int ra = first_use_alloc(&r2c_side, sb, s);
-                if (ra) return ra;
-                bytes += (int64_t)sb;
-            }
             a.side = static_cast<cx<T>*>(r2c_side);
             a.r2c_power = io.power ? 1 : 0;
             a.scale = io.scale;
