@@ -57,6 +57,9 @@ SIGNATURES = {
                                 _vp, _vp, _vp]),
     "mfft_lines_blocks_host": (_int, [_vp, _vp, _vp, _vp, _int, _dbl, _dbl, _vp, ctypes.POINTER(PeakParams), _int, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp]),
+    "mfft_lines_extract_host": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _dbl, _dbl, _vp, ctypes.POINTER(PeakParams),
+                                        _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_dbl)]),
+    "mfft_lines_gram_host": (_int, [_vp, _vp, _int, _dbl, _vp]),
     "mfft_lsq_normal_static": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "mfft_local_maxima": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp]),
     "mfft_exec_host_peaks": (_int, [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),

@@ -726,6 +726,10 @@ struct Plan {
     hipStream_t s_lines = nullptr; // mfft_lines_host runs on a stream of the plan, so sessions on other plans overlap
     double* d_lsq_part = nullptr;  // per-block partial sums of the line fit's normal equations (mfft_lines_host)
     size_t lsq_part_doubles = 0;
+    // samples a line search left on the device (mfft_lines_extract_host) for mfft_lines_gram_host
+    bool resident = false;
+    double* d_fit = nullptr;       // columns (64) | demodulation frequency (1) | normal equations (2*64*64 + 2*64 + 1) | partial sums
+    double* h_fit = nullptr;       // pinned mirror of the first three
 };
 
 // symmetric Hann window of m samples, np.hanning's formula, evaluated in long double
@@ -755,6 +759,8 @@ static void plan_free(Plan* p)
     if (p->ev_spec) (void)hipEventDestroy(p->ev_spec);
     if (p->d_norm) (void)hipFree(p->d_norm);
     if (p->d_lsq_part) (void)hipFree(p->d_lsq_part);
+    if (p->d_fit) (void)hipFree(p->d_fit);
+    if (p->h_fit) (void)hipHostFree(p->h_fit);
     p->s_spec = nullptr; p->s_lines = nullptr; p->ev_spec = nullptr; p->d_norm = nullptr; p->d_lsq_part = nullptr;
     for (void* q : {p->pin_in[0], p->pin_in[1], p->pin_out[0], p->pin_out[1], (void*)p->h_peaks, (void*)p->h_lines, (void*)p->h_spec})
         if (q) (void)hipHostFree(q);
@@ -1702,6 +1708,10 @@ static bool host_pinned(const void* h)
 struct LineSource {
     const void* h_x = nullptr;
     const AmpArgs* blocks = nullptr;      // one per signal of the batch
+    // centroid demodulation (streamlit_app_combined.py:203-209): a rough pass through this plan -- the same transform
+    // without MFFT_DEMOD -- gives mu = sum(omega S) / sum(S), which the main pass then demodulates by; mu goes to *h_mu
+    mfft_plan rough = nullptr;
+    double* h_mu = nullptr;
 };
 
 static int lines_run(mfft_plan plan, const LineSource& src, double scale, double mu, double t0, double dt,
@@ -1729,9 +1739,20 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
         }
     }
     if (p->batch > 65535) { set_error("at most 65535 spectra per call"); return MFFT_E_UNSUPPORTED; }
+    Plan* rough = reinterpret_cast<Plan*>(src.rough);
+    if (rough) {
+        if (!src.h_mu || rough == p) { set_error("null argument"); return MFFT_E_INVALID; }
+        if (!(p->flags & MFFT_DEMOD) || rough->flags != (p->flags & ~(uint32_t)MFFT_DEMOD) || rough->n != p->n || rough->n_in != p->n_in ||
+            rough->batch != 1 || p->batch != 1 || rough->dtype != p->dtype || rough->device != p->device || rough->kind == Plan::COLUMNS ||
+            rough->lin.batch_stride || rough->lin.seg || rough->lout.batch_stride || rough->lout.seg) {
+            set_error("the rough pass takes the same one-signal plan without MFFT_DEMOD");
+            return MFFT_E_INVALID;
+        }
+    }
     DeviceGuard g(p->device);
     if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
     std::lock_guard<std::mutex> lock(p->mu);
+    p->resident = false;
     const size_t rs = real_size(p->dtype);
     const int64_t B = p->batch, n = p->n, n_in = p->n_in;
     const int want = prm->want;
@@ -1806,7 +1827,21 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
     } else {
         MFFT_HIP(hipMemcpyAsync(d, h_up, h_gram ? up_bytes : in_bytes, hipMemcpyHostToDevice, sm));
     }
-    int rc = plan_exec_ordered(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, sm);
+    int rc = MFFT_OK;
+    if (rough) {
+        // rough spectrum -> its sum and first moment -> mu, on the same resident samples
+        std::lock_guard<std::mutex> rough_lock(rough->mu);
+        if (!rough->d_out) MFFT_HIP(hipMalloc(&rough->d_out, out_bytes));
+        rc = plan_exec_ordered(rough, d + o_x, rough->d_out, scale, 0.0, 0.0, 1.0, d_stats, sm);
+        if (rc) return rc;
+        MFFT_HIP(hipMemcpyAsync(h_down + (o_stats - o_down), d_stats, sizeof(double) * 3, hipMemcpyDeviceToHost, sm));
+        MFFT_HIP(hipStreamSynchronize(sm));
+        const double* st = reinterpret_cast<const double*>(h_down + (o_stats - o_down));
+        const double two_pi = 2.0 * 3.141592653589793;
+        mu = st[1] > 0.0 ? (two_pi / ((double)n * prm->dt)) * st[2] / st[1] : 0.0;     // the reference's own expression, in its order
+        *src.h_mu = mu;
+    }
+    rc = plan_exec_ordered(p, d + o_x, p->d_out, scale, mu, t0, dt, d_stats, sm);
     if (rc) return rc;
     // The spectra leave on a stream of their own as soon as the transform is done -- normalised into a
     // copy, because the line search reads the unnormalised ones meanwhile -- and land in pinned memory
@@ -1914,6 +1949,7 @@ static int lines_run(mfft_plan plan, const LineSource& src, double scale, double
     memcpy(h_count, h_down + (o_n - o_down), sizeof(int) * (size_t)B);
     if (h_gram) memcpy(h_gram, h_down + (o_gram - o_down), sizeof(double) * (size_t)B * nres);
     if (pooled) CopyPool::out().wait(ticket);
+    p->resident = src.blocks != nullptr && p->dtype == MFFT_C128 && !(p->flags & MFFT_REAL_IN);   // samples and time grid stay in d_lines
     return MFFT_OK;
 }
 
@@ -1942,6 +1978,62 @@ int mfft_lines_blocks_host(mfft_plan plan, const double* h_w, const double* h_c0
     LineSource src;
     src.blocks = blocks.data();
     return lines_run(plan, src, scale, 0.0, 0.0, 1.0, h_times, prm, normalize, h_S, h_stats, h_idx, h_omega_hat, h_height, h_count, h_gram);
+}
+
+int mfft_lines_extract_host(mfft_plan plan, mfft_plan rough_plan, const double* h_w, const double* h_c0, const double* h_vrow,
+                            int nk, double hbar, double scale, double t0, double dt, const double* h_times,
+                            const mfft_peak_params* prm, void* h_S, double* h_stats, int64_t* h_idx, double* h_omega_hat,
+                            double* h_height, int32_t* h_count, double* h_mu)
+{
+    if (!plan || !h_w || !h_c0 || !h_vrow || !h_mu) { set_error("null argument"); return MFFT_E_INVALID; }
+    if (reinterpret_cast<Plan*>(plan)->batch != 1) { set_error("one signal per call"); return MFFT_E_INVALID; }
+    AmpArgs block;
+    const int rc = amp_args(&block, h_w, h_c0, h_vrow, nk, hbar);
+    if (rc) return rc;
+    *h_mu = 0.0;
+    LineSource src;
+    src.blocks = &block;
+    src.rough = rough_plan;
+    src.h_mu = h_mu;
+    return lines_run(plan, src, scale, 0.0, t0, dt, h_times, prm, 0, h_S, h_stats, h_idx, h_omega_hat, h_height, h_count, nullptr);
+}
+
+int mfft_lines_gram_host(mfft_plan plan, const double* h_E, int m, double mu, double* h_gram)
+{
+    if (!plan || !h_E || !h_gram) { set_error("null argument"); return MFFT_E_INVALID; }
+    if (m < 1 || m > 64) { set_error("1 <= m <= 64 columns"); return MFFT_E_INVALID; }
+    Plan* p = reinterpret_cast<Plan*>(plan);
+    DeviceGuard g(p->device);
+    if (!g.ok) { set_error("cannot select the plan's device"); return MFFT_E_HIP; }
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (!p->resident || !p->d_lines || !p->s_lines || p->batch != 1) {
+        set_error("no resident samples: mfft_lines_extract_host / mfft_lines_blocks_host of this plan must come first");
+        return MFFT_E_INVALID;
+    }
+    constexpr size_t kCols = 64, kRes = 2 * kCols * kCols + 2 * kCols + 1;
+    const int nchunk = (m + kLsqCols - 1) / kLsqCols;
+    const size_t part = (size_t)64 * 4 * kLsqSlot * 64;                    // 64 columns x 4 chunks x 64 sample blocks
+    const size_t head = kCols + 1 + kRes;
+    if (!p->d_fit) {
+        MFFT_HIP(hipMalloc((void**)&p->d_fit, (head + part) * sizeof(double)));
+        MFFT_HIP(hipHostMalloc((void**)&p->h_fit, head * sizeof(double), hipHostMallocDefault));
+    }
+    const size_t nres = 2 * (size_t)m * m + 2 * (size_t)m + 1;
+    const size_t in_bytes = (size_t)p->n_in * 2 * sizeof(double);
+    hipStream_t sm = p->s_lines;
+    for (int i = 0; i < m; ++i) p->h_fit[i] = h_E[i];
+    p->h_fit[kCols] = mu;
+    MFFT_HIP(hipMemcpyAsync(p->d_fit, p->h_fit, (kCols + 1) * sizeof(double), hipMemcpyHostToDevice, sm));
+    const int rc = lsq_normal_launch(p->d_lines, (p->flags & MFFT_HANN) ? static_cast<const double*>(p->d_win) : nullptr,
+                                     reinterpret_cast<const double*>(p->d_lines + align256(in_bytes)), p->n_in, 1, p->d_fit + kCols,
+                                     p->d_fit, m, p->d_fit + kCols + 1, p->d_fit + head, part, sm, "mfft_lines_gram_host");
+    (void)nchunk;
+    if (rc) { (void)hipStreamSynchronize(sm); return rc; }
+    hipError_t e = hipMemcpyAsync(p->h_fit + kCols + 1, p->d_fit + kCols + 1, nres * sizeof(double), hipMemcpyDeviceToHost, sm);
+    if (e == hipSuccess) e = hipStreamSynchronize(sm);
+    if (e != hipSuccess) return hip_fail(e, "mfft_lines_gram_host", __FILE__, __LINE__);
+    memcpy(h_gram, p->h_fit + kCols + 1, nres * sizeof(double));
+    return MFFT_OK;
 }
 
 int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const double* d_max, int dtype,

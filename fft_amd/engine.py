@@ -230,6 +230,51 @@ class Plan:
                 hgt.ctypes.data, cnt.ctypes.data, gram.ctypes.data if gram is not None else None))
         return {"S": S, "stats": stats, "idx": idx, "omega_hat": om, "height": hgt, "count": cnt, "gram": gram}
 
+    def exec_host_extract(self, rough, w, c0, vrow, times, *, hbar: float = 1.0, axis_dt: float, guard: float, want: int,
+                          scale: float = 1.0, t0: float = 0.0, dt: float = 1.0, columns_of=None):
+        """The device passes of fft_extract_E_p in two calls on samples that stay on the device
+        (mfft_lines_extract_host, mfft_lines_gram_host): the return amplitude sum_k vrow[k] exp(-i w[k] t / hbar) c0[k]
+        on the grid `times`, the centroid mu from a rough pass through the plan `rough` (None: no demodulation), the
+        demodulated spectrum and its |omega|-deduplicated peaks; then, if ``columns_of(result)`` returns line positions,
+        the normal equations of the fit on those columns.  Returns the dict of exec_host_lines plus ``mu`` and ``gram``
+        (2 m m + 2 m + 1 doubles, or None).  One signal per plan."""
+        if self._h is None or (rough is not None and rough._h is None):
+            raise ValueError("plan already destroyed")
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        c0 = np.ascontiguousarray(c0, dtype=np.complex128)
+        vrow = np.ascontiguousarray(vrow, dtype=np.complex128)
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        if self.batch != 1 or w.ndim != 1 or c0.shape != w.shape or vrow.shape != w.shape:
+            raise ValueError("block data must be three vectors of one length, for a plan of one signal")
+        if t.shape[0] != self.n_in:
+            raise ValueError("`times` must have one entry per sample")
+        want = int(want)
+        prm = _lib.PeakParams(float(axis_dt), 0.0, float(guard), 0, 1, want)
+        S = hostmem.empty((1, self.n), self.out_dtype)
+        stats = np.zeros((1, 3), dtype=np.float64)
+        idx = np.empty((1, max(want, 1)), dtype=np.int64)
+        om = np.empty((1, max(want, 1)), dtype=np.float64)
+        hgt = np.empty((1, max(want, 1)), dtype=np.float64)
+        cnt = np.zeros(1, dtype=np.int32)
+        mu = ctypes.c_double(0.0)
+        lib = _lib.load()
+        with self._lock:
+            _lib.check(lib.mfft_lines_extract_host(
+                self._h, rough._h if rough is not None else None, w.ctypes.data, c0.ctypes.data, vrow.ctypes.data,
+                int(w.shape[0]), float(hbar), float(scale), float(t0), float(dt), t.ctypes.data, ctypes.byref(prm),
+                S.ctypes.data, stats.ctypes.data, idx.ctypes.data, om.ctypes.data, hgt.ctypes.data, cnt.ctypes.data,
+                ctypes.byref(mu)))
+            res = {"S": S, "stats": stats, "idx": idx, "omega_hat": om, "height": hgt, "count": cnt, "mu": float(mu.value),
+                   "gram": None}
+            cols = columns_of(res) if columns_of is not None else None
+            if cols is not None:
+                E = np.ascontiguousarray(cols, dtype=np.float64)
+                m = int(E.shape[0])
+                gram = np.empty(2 * m * m + 2 * m + 1, dtype=np.float64)
+                _lib.check(lib.mfft_lines_gram_host(self._h, E.ctypes.data, m, float(mu.value), gram.ctypes.data))
+                res["gram"] = gram
+        return res
+
     # -- lifetime ---------------------------------------------------------------
     def destroy(self):
         if getattr(self, "_h", None) is not None and self._h.value:

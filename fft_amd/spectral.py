@@ -391,14 +391,9 @@ def fft_from_timeseries_blocks(
 
 # --------------------------------------------------------------------------- estimator B
 
-def _amplitude_on_device(H, site, times, hbar=1.0):
-    """f(t_j) = <site| exp(-i H t_j / hbar) |site> for every t_j, evaluated on the GPU.
-
-    The eigendecomposition of the small Hermitian block stays on the host (L <= 10 in
-    the apps); the per-time work -- the Python loop of evolve_state_in_H
-    (final2.py:85-91, streamlit_app_combined.py:86-93), the apps' own hot loop -- runs
-    as one kernel: f_j = V[site, :] . (exp(-i w t_j / hbar) * c0),  c0 = V^H |site>."""
-    import ctypes
+def _eigen_data(H, site):
+    """(w, c0, vrow) of the return amplitude <site| exp(-i H t) |site> = sum_k vrow[k] exp(-i w[k] t) c0[k]:
+    eigenvalues, V^H |site> and V[site, :] of the small Hermitian block (host: L <= 10 in the apps)."""
     H = np.asarray(H)
     if H.ndim != 2 or H.shape[0] != H.shape[1]:
         raise ValueError("H must be a square matrix")
@@ -410,12 +405,24 @@ def _amplitude_on_device(H, site, times, hbar=1.0):
     psi0[site] = 1.0
     c0 = np.ascontiguousarray(V.conj().T @ psi0, dtype=np.complex128)
     vrow = np.ascontiguousarray(V[site, :], dtype=np.complex128)
+    return w, c0, vrow
+
+
+def _amplitude_on_device(H, site, times, hbar=1.0):
+    """f(t_j) = <site| exp(-i H t_j / hbar) |site> for every t_j, evaluated on the GPU.
+
+    The eigendecomposition of the small Hermitian block stays on the host (L <= 10 in
+    the apps); the per-time work -- the Python loop of evolve_state_in_H
+    (final2.py:85-91, streamlit_app_combined.py:86-93), the apps' own hot loop -- runs
+    as one kernel: f_j = V[site, :] . (exp(-i w t_j / hbar) * c0),  c0 = V^H |site>."""
+    import ctypes
+    w, c0, vrow = _eigen_data(H, site)
     t = np.ascontiguousarray(times, dtype=np.float64)
     out = np.empty(t.shape[0], dtype=np.complex128)
     lib = _lib.load()
     _lib.check(lib.mfft_return_amplitude_host(
         out.ctypes.data, t.shape[0], t.ctypes.data, 0.0, 0.0, w.ctypes.data, c0.ctypes.data,
-        vrow.ctypes.data, int(H.shape[0]), float(hbar)))
+        vrow.ctypes.data, int(w.shape[0]), float(hbar)))
     return out
 
 
@@ -449,46 +456,47 @@ def return_amplitude_block_general(K, J, bottom_m, site, times, hbar=1.0):
 def fft_extract_E_p(Htop, site, times, n_peaks=3, pad=16, use_hann=True, demod=True):
     """(E_est ascending, p_est, omega, S, mu) from f_ss(t) by FFT, optional centroid
     demodulation and a 2^k sign-search least squares; see
-    streamlit_app_combined.py:190-251."""
-    f_t = return_amplitude(Htop, site=site, times=times)
+    streamlit_app_combined.py:190-251.
+
+    f_ss(t) is generated on the device and stays there: one call runs the rough pass (only its two sums are
+    looked at), the demodulated main pass and the peak search on its spectrum; a second one reduces the Gram
+    matrix of the sign search on the same samples."""
+    w, c0, vrow = _eigen_data(Htop, site)
     times = np.asarray(times, float)
     dt = float(times[1] - times[0])
-    win = _window_of(f_t, use_hann)
-    n0 = len(f_t)
+    n0 = times.shape[0]
     nfft = int(pad * n0)
-
-    # centroid of the rough spectrum: only two sums come back from the device
-    mu = 0.0
-    if demod:
-        _, _, ssum, centroid_bins = power_spectrum(f_t, nfft, dt, use_hann=bool(use_hann),
-                                                   want_spectrum=False)
-        if ssum > 0:
-            mu = float((TWO_PI / (nfft * dt)) * centroid_bins / ssum)
     omega = _omega_axis(nfft, dt).copy()
-    # main pass: demodulated spectrum plus, on its device copy, the local maxima ranked by height and
-    # de-duplicated on |omega| (the first n_peaks the reference's loop keeps are the first n_peaks it
-    # picks: it walks the candidates by decreasing height)
     tol = TWO_PI / (times[-1] - times[0] + 1e-12)
-    shift = mu if (demod and mu != 0.0) else 0.0
-    flags = _lib.POWER | _lib.STATS | (_lib.HANN if use_hann else 0) | (_lib.DEMOD if shift != 0.0 else 0)
-    plan = cached_plan(nfft, n0, 1, _lib.C128, flags)
-    res = plan.exec_host_lines(np.ascontiguousarray(f_t, dtype=np.complex128), axis_dt=dt, guard=0.6 * tol,
-                               want=max(int(n_peaks), 1), mode=1, scale=dt, mu=shift, t0=float(times[0]), dt=dt)
-    S = res["S"][0]
-    chosen = [int(i) for i in res["idx"][0, :int(res["count"][0])]][:max(int(n_peaks), 0)]
-    if len(chosen) == 0:
-        return np.array([]), np.array([]), omega, S, mu
-    mags = np.sort(np.unique(np.round(np.abs(omega[chosen]), 12)))[:n_peaks]
+    flags = _lib.POWER | _lib.STATS | (_lib.HANN if use_hann else 0)
+    rough = cached_plan(nfft, n0, 1, _lib.C128, flags) if demod else None
+    plan = cached_plan(nfft, n0, 1, _lib.C128, flags | (_lib.DEMOD if demod else 0))
+    found = {}
 
-    # Every fit of the 2^k sign search uses k of the 2k columns exp(-i(+-|omega|)t): reduce the
-    # Gram matrix of all 2k once on the device and read each fit off its sub-block.
+    def columns_of(res):
+        # local maxima ranked by height and de-duplicated on |omega| (the first n_peaks the reference's loop keeps
+        # are the first n_peaks it picks: it walks the candidates by decreasing height); every fit of the 2^k sign
+        # search uses k of the 2k columns exp(-i(+-|omega|)t): one Gram matrix of all 2k, each fit read off a sub-block
+        chosen = [int(i) for i in res["idx"][0, :int(res["count"][0])]][:max(int(n_peaks), 0)]
+        if len(chosen) == 0:
+            return None
+        mags = np.sort(np.unique(np.round(np.abs(omega[chosen]), 12)))[:n_peaks]
+        if 2 * len(mags) > 64:
+            raise ValueError("at most 32 peaks can enter the sign search")
+        found["mags"] = mags
+        return np.concatenate((mags, -mags))
+    res = plan.exec_host_extract(rough, w, c0, vrow, times, axis_dt=dt, guard=0.6 * tol, want=max(int(n_peaks), 1),
+                                 scale=dt, t0=float(times[0]), dt=dt, columns_of=columns_of)
+    S = res["S"][0]
+    mu = res["mu"]
+    if res["gram"] is None:
+        return np.array([]), np.array([]), omega, S, mu
+    mags = found["mags"]
     k = len(mags)
-    if 2 * k > 64:
-        raise ValueError("at most 32 peaks can enter the sign search")
-    demod_mu = mu if (demod and mu != 0.0) else 0.0
-    G, r, yy = _normal_equations(f_t, win if use_hann else None, times, np.concatenate((mags, -mags)),
-                                 mu=demod_mu)
-    signs, best_p = _sign_search(G, r, yy, k)
+    g = res["gram"]
+    G = g[:8 * k * k].view(np.complex128).reshape(2 * k, 2 * k)
+    r = g[8 * k * k:8 * k * k + 4 * k].view(np.complex128)
+    signs, best_p = _sign_search(G, r, float(g[-1]), k)
     best_E = signs * mags
     E_phys = best_E - mu
     order = np.argsort(E_phys)

@@ -277,6 +277,24 @@ int mfft_normalize_by_max(const void* d_in, void* d_out, int64_t count, const do
 
 /* out[b][c][r] = in[b][r][c]  for `batch` matrices of rows x cols complex elements
  * (local re-layout step of the pencil / four-step decompositions). */
+/* fft_extract_E_p's device passes (streamlit_app_combined.py:190-231) on samples that never leave the device: the return
+ * amplitude of ONE small Hermitian block is generated into the plan's input (as mfft_lines_blocks_host does), a rough
+ * pass through `rough_plan` -- the same one-signal plan without MFFT_DEMOD -- gives the centroid
+ *     mu = (2 pi / (n dt)) * sum_k f_k S0[k] / sum_k S0[k]      (0 when the sum is not positive;  :204-207)
+ * and the main pass through `plan` (with MFFT_DEMOD) transforms the samples times exp(+i mu (t0 + j dt)) (:209-215) and
+ * runs the line search on its spectrum.  rough_plan NULL: no demodulation (plan without MFFT_DEMOD, *h_mu = 0).  h_S receives
+ * the unnormalised spectrum; the other outputs are mfft_lines_host's.  The samples and the time grid stay on the device
+ * for mfft_lines_gram_host. */
+int mfft_lines_extract_host(mfft_plan plan, mfft_plan rough_plan, const double* h_w, const double* h_c0, const double* h_vrow,
+                            int nk, double hbar, double scale, double t0, double dt, const double* h_times,
+                            const mfft_peak_params* prm, void* h_S, double* h_stats, int64_t* h_idx, double* h_omega_hat,
+                            double* h_height, int32_t* h_count, double* h_mu);
+/* Normal equations of the windowed line fit (streamlit_app_combined.py:233-246; mfft_lsq_normal_host's G, r, yy) for m
+ * columns exp(-i E_a t) against the samples the last mfft_lines_extract_host / mfft_lines_blocks_host call of this
+ * one-signal plan left on the device, demodulated by mu.  h_gram: 2 m m + 2 m + 1 doubles (G row-major re/im, r re/im, yy).
+ * MFFT_E_INVALID when the plan holds no such samples. */
+int mfft_lines_gram_host(mfft_plan plan, const double* h_E, int m, double mu, double* h_gram);
+
 /* Page-locked host memory the device reads and writes directly.  No counterpart in the reference (its arrays are
  * numpy's): the host layer hands the spectra of fft_from_timeseries / fft_extract_E_p (final2.py:146, 188) back in
  * such blocks, so that mfft_lines_host downloads them in place instead of into a staging buffer and copying again.
