@@ -677,3 +677,47 @@ def test_spectra_come_back_in_recycled_page_locked_arrays():
     S4 = sp.fft_from_timeseries(f2, times, n_levels=1, pad_factor=32)[3]
     S4[:10] = 7.0                             # writable like any numpy array
     assert S4.flags.writeable and S4.dtype == np.float64 and S4.shape == (256032,)
+
+
+def test_resident_extract_passes_against_the_separate_calls():
+    """mfft_lines_extract_host / mfft_lines_gram_host (the device passes of fft_extract_E_p,
+    streamlit_app_combined.py:197-246, on samples that stay on the device) against the same steps made one by one
+    through the host: mu bit for bit, spectrum, picked bins, normal equations; and what the entry points refuse."""
+    import fft_amd as fa
+    from fft_amd import _lib, spectral as sp
+    from fft_amd.npfft import cached_plan
+    H = np.array([[0.3, 1.0, 0.0], [1.0, -0.2, 0.7], [0.0, 0.7, 0.5]])
+    times = np.arange(0.0, 15.0 + 0.01, 0.01)
+    n0, pad, dt = times.shape[0], 16, 0.01
+    nfft = pad * n0
+    flags = _lib.POWER | _lib.STATS | _lib.HANN
+    with fa.Plan(nfft, n_in=n0, batch=1, dtype=fa.C128, flags=flags | _lib.DEMOD) as main, \
+            fa.Plan(nfft, n_in=n0, batch=1, dtype=fa.C128, flags=flags) as rough, \
+            fa.Plan(nfft, n_in=n0 - 1, batch=1, dtype=fa.C128, flags=flags) as other:
+        w, c0, vrow = sp._eigen_data(H, 0)
+        tol = sp.TWO_PI / (times[-1] - times[0] + 1e-12)
+        gram0 = np.empty(2 * 4 + 2 * 2 + 1)
+        E2 = np.array([0.4, -0.4])
+        with pytest.raises((ValueError, fa.MfftError), match="no resident samples"):
+            _lib.check(_lib.load().mfft_lines_gram_host(main._h, E2.ctypes.data, 2, 0.0, gram0.ctypes.data))
+        with pytest.raises((ValueError, fa.MfftError), match="same one-signal plan"):
+            main.exec_host_extract(other, w, c0, vrow, times, axis_dt=dt, guard=0.6 * tol, want=3, scale=dt, t0=0.0, dt=dt)
+        res = main.exec_host_extract(rough, w, c0, vrow, times, axis_dt=dt, guard=0.6 * tol, want=3, scale=dt,
+                                     t0=float(times[0]), dt=dt, columns_of=lambda r: np.array([1.1, 0.3, -1.1, -0.3]))
+        # the same steps one by one
+        f_t = sp.return_amplitude(H, 0, times)
+        assert rel_l2(f_t, so.return_amplitude_top(H, 0, times)) < 1e-13
+        _, _, ssum, cen = sp.power_spectrum(f_t, nfft, dt, use_hann=True, want_spectrum=False)
+        mu = float((sp.TWO_PI / (nfft * dt)) * cen / ssum)
+        assert res["mu"] == mu and mu != 0.0
+        S, _, _, _ = sp.power_spectrum(f_t, nfft, dt, use_hann=True, mu=mu, t0=float(times[0]))
+        assert rel_l2(res["S"][0], S) < 1e-13
+        G, r, yy = sp._normal_equations(f_t, np.hanning(n0), times, np.array([1.1, 0.3, -1.1, -0.3]), mu=mu)
+        g = res["gram"]
+        assert rel_l2(g[:32].view(np.complex128).reshape(4, 4), G) < 1e-12
+        assert rel_l2(g[32:40].view(np.complex128), r) < 1e-12 and abs(g[-1] - yy) < 1e-12 * yy
+        # without demodulation: no rough plan, mu = 0
+        res0 = rough.exec_host_extract(None, w, c0, vrow, times, axis_dt=dt, guard=0.6 * tol, want=3, scale=dt, t0=0.0, dt=dt)
+        assert res0["mu"] == 0.0 and res0["gram"] is None
+        S0, _, _, _ = sp.power_spectrum(f_t, nfft, dt, use_hann=True)
+        assert rel_l2(res0["S"][0], S0) < 1e-13

@@ -254,6 +254,24 @@ int main()
         for (size_t i = 0; i < S2.size(); ++i) worst = std::fmax(worst, std::fabs(S2[i] - static_cast<const double*>(S)[i]));
         REQUIRE(worst == 0.0);                                                  // the page-locked and the pageable destination agree
         REQUIRE(mfft_host_free(S) == MFFT_OK && mfft_host_free(nullptr) == MFFT_OK);
+        // the other app's estimator: rough pass -> centroid -> demodulated pass -> peaks, then the fit on resident samples
+        mfft_plan main1 = nullptr, rough1 = nullptr;
+        REQUIRE(mfft_plan_1d(&main1, n, n0, 1, MFFT_C128, MFFT_HANN | MFFT_POWER | MFFT_STATS | MFFT_DEMOD) == MFFT_OK);
+        REQUIRE(mfft_plan_1d(&rough1, n, n0, 1, MFFT_C128, MFFT_HANN | MFFT_POWER | MFFT_STATS) == MFFT_OK);
+        const double Ecols[4] = {1.7, 0.3, -1.7, -0.3};
+        std::vector<double> g4(2 * 16 + 8 + 1);
+        double mu1 = -1.0;
+        REQUIRE(mfft_lines_gram_host(main1, Ecols, 4, 0.0, g4.data()) == MFFT_E_INVALID);          // nothing resident yet
+        REQUIRE(mfft_lines_extract_host(main1, plan, w.data(), c0.data(), vrow.data(), nk, 1.0, dt, 0.0, dt, t.data(), &prm, S2.data(),
+                                        stats.data(), idx.data(), om.data(), hgt.data(), cnt.data(), &mu1) == MFFT_E_INVALID);   // a batch plan as rough pass
+        for (int rep = 0; rep < 2; ++rep)
+            REQUIRE(mfft_lines_extract_host(main1, rough1, w.data(), c0.data(), vrow.data(), nk, 1.0, dt, 0.0, dt, t.data(), &prm, S2.data(),
+                                            stats.data(), idx.data(), om.data(), hgt.data(), cnt.data(), &mu1) == MFFT_OK);
+        REQUIRE(std::isfinite(mu1) && mu1 != 0.0 && cnt[0] >= 1);
+        REQUIRE(mfft_lines_gram_host(main1, Ecols, 4, mu1, g4.data()) == MFFT_OK);
+        REQUIRE(g4.back() > 0.0 && std::fabs(g4[0] - g4[2 * 5]) < 1e-9 * g4[0]);                    // yy > 0, equal diagonal entries
+        REQUIRE(mfft_lines_gram_host(main1, Ecols, 65, mu1, g4.data()) == MFFT_E_INVALID);
+        REQUIRE(mfft_plan_destroy(main1) == MFFT_OK && mfft_plan_destroy(rough1) == MFFT_OK);
         REQUIRE(mfft_host_alloc(nullptr, 8) == MFFT_E_INVALID);
         REQUIRE(mfft_plan_destroy(plan) == MFFT_OK);
     }
