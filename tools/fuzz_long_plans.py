@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised sweep of real-input plans above one LDS residency (the packed route with the split fused into the last
 pass) against np.fft.fft in float64: lengths 2^15 .. 2^24, even and odd sample counts (odd ones take the promoting
-route), batches, Hann / power / statistics, both precisions, random MFFT_SPLIT of the half-length plan.
-    python tools/fuzz_real_input.py [FIRST_SEED [LAST_SEED [CASES_PER_SEED]]]"""
+route), batches, Hann / power / statistics, both precisions, random MFFT_SPLIT of the half-length plan.  With
+COMPLEX=1 the samples are complex: the windowed / zero-padded first passes of the tile kernels at random splits.
+    python tools/fuzz_long_plans.py [FIRST_SEED [LAST_SEED [CASES_PER_SEED [COMPLEX]]]]"""
 import os
 import sys
 
@@ -34,6 +35,7 @@ def random_split(rng, log2m, dtype):
 def main():
     argv = [int(v) for v in sys.argv[1:]]
     first, last, cases = (argv + [1])[0], (argv + [1, 4])[1], (argv + [1, 4, 25])[2]
+    cplx = bool((argv + [1, 4, 25, 0])[3])
     failures, count, refused = [], 0, 0
     worst = {0: 0.0, 1: 0.0}
     for seed in range(first, last + 1):
@@ -47,19 +49,21 @@ def main():
             if rng.random() < 0.8:
                 n_in -= n_in & 1
             n_in = max(n_in, 2)
-            flags = fa.REAL_IN | (fa.HANN if rng.random() < 0.5 else 0)
+            flags = (0 if cplx else fa.REAL_IN) | (fa.HANN if rng.random() < 0.5 else 0)
             power = rng.random() < 0.5
             stats = power and rng.random() < 0.5
             flags |= (fa.POWER if power else 0) | (fa.STATS if stats else 0)
-            split = random_split(rng, log2n - 1, dtype) if n_in % 2 == 0 else None
+            split = random_split(rng, log2n, dtype) if cplx else (random_split(rng, log2n - 1, dtype) if n_in % 2 == 0 else None)
             if split:
                 os.environ["MFFT_SPLIT"] = split
             else:
                 os.environ.pop("MFFT_SPLIT", None)
             rdt = np.float32 if dtype == 0 else np.float64
             x = rng.standard_normal((batch, n_in)).astype(rdt)
+            if cplx:
+                x = (x + 1j * rng.standard_normal((batch, n_in))).astype(np.complex64 if dtype == 0 else np.complex128)
             scale = float(rng.choice([1.0, 0.01]))
-            xw = x.astype(np.float64) * (np.hanning(n_in) if flags & fa.HANN else 1.0)
+            xw = x.astype(np.complex128 if cplx else np.float64) * (np.hanning(n_in) if flags & fa.HANN else 1.0)
             ref = scale * np.fft.fft(xw, n, axis=-1)
             if power:
                 ref = np.abs(ref) ** 2
@@ -92,7 +96,7 @@ def main():
         print(f"seed {seed} done, {count} cases, {refused} splits refused, {len(failures)} failures", flush=True)
     for f in failures:
         print("FAIL", f)
-    print(f"fuzz_real_input {'ok' if not failures else 'FAILED'} {count} cases; worst rel L2: float32 {worst[0]:.2e}, float64 {worst[1]:.2e}")
+    print(f"fuzz_long_plans {'ok' if not failures else 'FAILED'} {count} cases; worst rel L2: float32 {worst[0]:.2e}, float64 {worst[1]:.2e}")
     return 1 if failures else 0
 
 
