@@ -328,6 +328,40 @@ def secondary_configs(with_cpu):
         del x, y
     except Exception as exc:                                  # noqa: BLE001 - a side measurement must not sink the headline
         out["config3_1d_2pow24_c64"] = {"error": repr(exc)[:200]}
+    try:
+        # the reference's own call shapes next to the plain transform (parity-test cases with a clock on them): a real
+        # signal (np.fft.fft of real f_t, final2.py:142-143) above one LDS residency -- half-length plan, split fused into
+        # its last pass -- and a Hann-windowed, zero-padded complex64 batch (final2.py:139-143) against the plain one
+        routes = {}
+        n, batch = 1 << 22, 4
+        xr = torch.randn((batch, n), dtype=torch.float64, device="cuda")
+        xc = torch.view_as_complex(torch.randn((batch, n, 2), dtype=torch.float64, device="cuda"))
+        y = torch.empty((batch, n), dtype=torch.complex128, device="cuda")
+        with fft_amd.Plan(n, batch=batch, dtype=fft_amd.C128, flags=fft_amd.REAL_IN) as pr, fft_amd.Plan(n, batch=batch, dtype=fft_amd.C128) as pc:
+            t_r = timed(lambda: pr.exec(xr, y, stream=stream), 10)
+            ks = [0, 1, 255, n // 4 + 3, n // 2 - 1, n // 2, n // 2 + 1, n - 1]
+            err = _check_1d(xr[1].to(torch.complex128), y[1], ks)
+            t_c = timed(lambda: pc.exec(xc, y, stream=stream), 10)
+        routes["real_input_2pow22_x4_f64"] = {"ms": t_r * 1e3, "ms_complex_input_same_length": t_c * 1e3, "ratio": t_r / t_c,
+                                              "verified_max_err_over_rms": err, "verified_bins": len(ks)}
+        del xr, xc, y
+        n, n_in, batch = 1 << 18, 200000, 256          # (an odd count, whose signals start off the 16-byte grid, costs ~10 %)
+        x = torch.view_as_complex(torch.randn((batch, n, 2), dtype=torch.float32, device="cuda"))
+        y = torch.empty((batch, n), dtype=torch.complex64, device="cuda")
+        xin = x[:, :n_in].contiguous()
+        with fft_amd.Plan(n, n_in=n_in, batch=batch, dtype=fft_amd.C64, flags=fft_amd.HANN) as pw, fft_amd.Plan(n, batch=batch, dtype=fft_amd.C64) as pp:
+            t_w = timed(lambda: pw.exec(xin, y, stream=stream), 10)
+            xw = torch.zeros(n, dtype=torch.complex128, device="cuda")
+            xw[:n_in] = xin[3].to(torch.complex128) * torch.from_numpy(np.hanning(n_in)).cuda()
+            err = _check_1d(xw, y[3], ks=[0, 1, 777, n // 3, n // 2, n - 2, n - 1])
+            t_p = timed(lambda: pp.exec(x, y, stream=stream), 10)
+        routes["hann_zero_padded_2pow18_x256_c64"] = {"ms": t_w * 1e3, "ms_plain_full_length": t_p * 1e3, "ratio": t_w / t_p,
+                                                     "n_in": n_in, "verified_max_err_over_rms": err, "verified_bins": 7}
+        del x, y, xin
+        out["reference_call_shapes"] = routes
+    except Exception as exc:                                  # noqa: BLE001
+        out["reference_call_shapes"] = {"error": repr(exc)[:200]}
+    torch.cuda.empty_cache()
     comm, ops = fd.Comm(), fd.HipOps()
     try:
         n = 16384
