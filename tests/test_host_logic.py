@@ -305,3 +305,31 @@ def test_bench_abandoned_leg_exits_nonzero_and_still_prints_the_line(tmp_path):
     proc = subprocess.run([sys.executable, str(script), "1"], capture_output=True, timeout=60)
     assert proc.returncode == bench.EXIT_ABANDONED and not proc.stdout.strip()
     assert __import__("time").time() - t0 < 40
+
+
+def test_uniform_grid_check_is_numpy_allclose():
+    """The estimators' grid check (final2.py:133: np.allclose(np.diff(times), dt)) evaluated directly agrees with
+    np.allclose on uniform, jittered, broken and non-finite grids."""
+    import warnings
+    from fft_amd.spectral import _uniform
+    rng = np.random.default_rng(3)
+    grids = [np.diff(np.arange(8001) * 0.01), np.diff(np.linspace(0.0, 15.0, 1501)), np.full(10, 0.0), np.array([1e-9, 2e-9]),
+             np.r_[np.full(50, 0.01), 0.02], np.r_[np.full(50, 0.01), np.nan], np.r_[np.full(50, 0.01), np.inf],
+             np.array([np.inf, np.inf]), np.array([-np.inf, np.inf]), np.array([5.0])]
+    for scale in (1e-12, 1e-9, 1e-7, 1e-5, 1e-3):
+        grids.append(0.01 * (1.0 + scale * rng.standard_normal(200)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for g in grids:
+            assert _uniform(g) == bool(np.allclose(g, g[0])), g[-3:]
+
+
+def test_result_arrays_fall_back_to_numpy_without_the_device():
+    """fft_amd.hostmem hands out plain numpy arrays when no page-locked block can be had (no GPU here) and for
+    small arrays; shapes, dtypes and writability are numpy's."""
+    from fft_amd import hostmem
+    for shape, dt in (((3, 100000), np.float64), ((10,), np.float32), ((1, 256032), np.float64)):
+        a = hostmem.empty(shape, dt)
+        assert a.shape == shape and a.dtype == dt and a.flags.writeable and a.flags.c_contiguous
+        a[...] = 1.0
+    hostmem.release_free_blocks()
