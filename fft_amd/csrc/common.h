@@ -70,6 +70,7 @@ template <typename T> struct KArgs {
     // V_SEG: power-of-two segments as shifts.  Element j sits at (j >> lseg) * seg_stride +
     // (j & ((1 << lseg) - 1)); lseg = 30 describes a dense signal.
     int in_lseg, out_lseg;
+    int grid_over;         // host only: resident sets of workgroups to launch, 0 = the measured default (lds_grid_over)
 };
 
 // Segments the plain segmented variant (V_SEG) serves without staging: powers of two up to 2^30 that hold

@@ -652,6 +652,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #if MFFT_DIAG_STAMPS
     unsigned long long stamp_acc[16] = {};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    [[maybe_unused]] const unsigned long long diag_t0 = stamp_prev;
 #define MFFT_STAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now__ - stamp_prev; stamp_prev = now__; } while (0)
 #else
 #define MFFT_STAMP(k) do { } while (0)
@@ -1051,6 +1052,19 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         }
     }
 #if MFFT_DIAG_STAMPS
+    if constexpr (!DMA) {
+        // per workgroup: start and end in s_memtime ticks (the counters of different XCDs are not aligned: only
+        // differences inside one workgroup mean anything), XCC_ID and HW_ID of wave 0
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_diag_stamps[blockIdx.x * 16 + 0] = diag_t0;
+            g_diag_stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
+            g_diag_stamps[blockIdx.x * 16 + 2] = xcc;
+            g_diag_stamps[blockIdx.x * 16 + 3] = hw;
+        }
+    }
     if constexpr (DMA) {
         if (threadIdx.x == 0 && blockIdx.x < 2048) {
             for (int k = 0; k < 16; ++k) g_diag_stamps[blockIdx.x * 16 + k] = stamp_acc[k];
@@ -1126,7 +1140,46 @@ template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_f
 
 // persistent grid: resident workgroups per CU (queried once per kernel) x CUs, capped by the work
 int blocks_per_cu(const void* kernel, int block, size_t lds);
-int pick_grid(int per_cu, int64_t groups);
+int pick_grid(int per_cu, int64_t groups, int over = 1);
+
+// Resident sets of workgroups a launch asks for.  One set (a persistent grid: every workgroup strides over
+// the batch and pays for its tables once) leaves the CUs' different speeds uncorrected -- per-CU durations
+// of the same 32 trips spread by +-5 % -- while workgroups that each take a few trips are handed out by the
+// dispatcher as CUs become free.  What that gains against the per-workgroup start-up (tables, window
+// registers, the drain of the last stores) was measured per length and variant on 2^26 (complex64) /
+// 2^25 (complex128) points per launch, factors 1, 2, 4, 8, 16: the light variants gain 5..12 % at 8..16
+// sets, the windowed power variants from 512 points (window samples and twiddles in registers: the
+// heaviest start-up, two workgroups per CU) lose 3..15 % and keep one set; the LDS-DMA kernels gain 1..5 %
+// at two sets and lose from four.  Columns: log2 of the length.
+template <typename T, int LOG2N, int VAR, bool DMA> constexpr int lds_grid_over()
+{
+    if (DMA) return 2;
+    constexpr int L = LOG2N > 14 ? 14 : LOG2N;
+    //                                0   1   2   3   4   5   6   7   8   9  10  11  12  13  14
+    constexpr signed char c64[V_COUNT][15] = {
+        /* V_PLAIN            */ {16, 16, 16, 16, 16, 16, 16, 16, 16, 16,  8, 16,  8,  1,  1},
+        /* V_HANN_POWER       */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  1,  1,  8,  1,  1,  1},
+        /* V_GEN_CPLX         */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_GEN_POWER        */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_SEG              */ { 1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1},
+        /* V_WIN              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  8,  8,  1,  1,  1},
+        /* V_POW              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  8,  8,  4,  1,  1},
+        /* V_REAL             */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  1, 16,  8,  1,  1},
+        /* V_HANN_POWER_STATS */ {16, 16, 16, 16, 16,  1,  4,  8,  8,  1,  1,  1,  1,  1,  1},
+        /* V_POW_STATS        */ {16, 16, 16, 16, 16,  8,  8, 16, 16,  4,  8,  8,  4,  1,  1}};
+    constexpr signed char c128[V_COUNT][15] = {
+        /* V_PLAIN            */ {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16,  8, 16,  1,  1},
+        /* V_HANN_POWER       */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  1,  2,  1,  1,  1,  1},
+        /* V_GEN_CPLX         */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_GEN_POWER        */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_SEG              */ { 1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1},
+        /* V_WIN              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  4,  8,  8,  4,  1,  1},
+        /* V_POW              */ { 8,  8,  8,  8,  8,  8,  8,  8, 16, 16,  2,  1,  2,  1,  1},
+        /* V_REAL             */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_HANN_POWER_STATS */ { 8,  8,  8,  8,  8,  8,  8, 16, 16,  4,  2,  1,  1,  1,  1},
+        /* V_POW_STATS        */ { 8,  8,  8,  8,  8, 16,  8, 16, 16, 16,  1,  1,  1,  1,  1}};
+    return sizeof(T) == 4 ? c64[VAR][L] : c128[VAR][L];
+}
 
 // The LDS-DMA pipeline moves 16 bytes per lane: signals (and segments) must start on 16-byte boundaries.
 // MFFT_NO_DMA=1 in the environment selects the register-load form (A/B timing, tests).
@@ -1167,7 +1220,7 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
     }
     const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
     if (groups <= 0) return MFFT_OK;
-    if (grid <= 0) grid = pick_grid(per_cu, groups);
+    if (grid <= 0) grid = pick_grid(per_cu, groups, a.grid_over > 0 ? a.grid_over : lds_grid_over<T, LOG2N, VAR, DMA>());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;

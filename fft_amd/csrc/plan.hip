@@ -120,9 +120,9 @@ int blocks_per_cu(const void* kernel, int block, size_t lds)
     return per_cu;
 }
 
-int pick_grid(int per_cu, int64_t groups)
+int pick_grid(int per_cu, int64_t groups, int over)
 {
-    int64_t g = (int64_t)per_cu * device_cu_count();
+    int64_t g = (int64_t)per_cu * device_cu_count() * (over > 0 ? over : 1);
     if (g > groups) g = groups;
     if (g < 1) g = 1;
     return (int)g;
@@ -218,6 +218,8 @@ struct Pow2Engine {
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
     int narrow = 0;                     // tile width bits (TArgs::narrow)
+    int lds_over = 0;                   // MFFT_LDS_GRID_OVER at build (tuning aid): the same for the single-kernel transforms, 0 = per length and variant
+    int grid_over = 4;                  // MFFT_TILE_GRID_OVER at build (tuning aid): resident sets of workgroups a non-prefetching tile pass is launched with
     int tile_buf = -1;                  // MFFT_TILE_BUF at build (tuning aid): TArgs::buf of every pass; -1 = by tile width and data size
     bool table_window = false;          // MFFT_TABLE_WINDOW at build: windowed first passes read the window table (tuning aid)
     int64_t inner = 1;                  // column-batched: transform along the middle axis of (batch, n, inner)
@@ -339,6 +341,8 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     log2n = ilog2(n);
     table_window = getenv("MFFT_TABLE_WINDOW") != nullptr;
     if (const char* e = getenv("MFFT_TILE_BUF")) tile_buf = atoi(e);
+    if (const char* e = getenv("MFFT_LDS_GRID_OVER")) lds_over = atoi(e) < 0 ? 0 : atoi(e) > 64 ? 64 : atoi(e);
+    if (const char* e = getenv("MFFT_TILE_GRID_OVER")) grid_over = atoi(e) < 1 ? 1 : atoi(e) > 64 ? 64 : atoi(e);
     if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
     if (!is_pow2(inner)) { set_error("the inner extent of a column-batched transform must be a power of two"); return MFFT_E_UNSUPPORTED; }
     const int maxlog = dtype == MFFT_C64 ? kMaxLdsLog2C64 : kMaxLdsLog2C128;
@@ -475,6 +479,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.n_in = (int)io.n_in; a.n_out = (int)io.n_out;
         a.real_in = io.real_in; a.conj_in = io.conj_in; a.conj_out = io.conj_out;
         a.scale = io.scale;
+        a.grid_over = lds_over;
         const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n &&
                           io.in_seg == 0 && io.out_seg == 0;
         const bool bare_or_stats = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && full;
@@ -513,6 +518,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
             w.win = io.win;
             w.units = nb * n * (int64_t)sizeof(cx<T>) / 16;
             w.scale = io.scale;
+            w.grid_over = lds_over;
             if constexpr (sizeof(T) == 4) return launch_wave_c64(log2n, io.win != nullptr, io.power, io.real_in != 0, w, s);
             else return launch_wave_c128(log2n, io.win != nullptr, io.power, io.real_in != 0, w, s);
         }
@@ -602,6 +608,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.xcd = tile_log2c(dtype, gp.log2g, narrow) <= 2 ? 1 : 0;   // four-column tiles: neighbours share cache lines,
         if (a.xcd) a.nt = 0;                                         // which streaming accesses would not keep in L2
         // buffer-form accesses: four-column tiles always, wider ones while the plan's data is at most 128 MiB
+        a.grid_over = grid_over;
         a.buf = tile_buf >= 0 ? tile_buf
                               : ((tile_log2c(dtype, gp.log2g, narrow) <= 2 || (inner == 1 && work_bytes <= (size_t(128) << 20))) ? 12 : 0);
         a.scale = 1;

@@ -120,6 +120,7 @@ template <typename T> struct TArgs {
     int narrow;           // tile width bits (see launch_tile_mode)
     int nt;               // bit 0: non-temporal loads, bit 1: non-temporal stores (plain modes only)
     int xcd;              // 1: XCD-aware tile order (narrow tiles whose neighbours share cache lines)
+    int grid_over;        // host only: resident sets of workgroups the launch asks for (prefetching kernels always one)
     int buf;              // plain loads (bit 2) / four-column tiles' plain stores (bit 3) as buffer instructions: the tile's origin
                           // in the descriptor, the row group in the scalar offset, one 32-bit lane offset.  Needs a signal of
                           // less than 2^32 bytes (checked at launch).  Measured on MI355X against global loads with a scalar
@@ -297,6 +298,28 @@ template <typename T, int BLOCK, int MODE> constexpr int tile_min_waves()
     return (MFFT_TILE_OCC != 0 && sizeof(T) == 4 && plain && BLOCK <= 512) ? BLOCK / 128 : 1;
 }
 
+// Prefetch.  A complex128 tile of 512 points x 16 columns or 256 x 32 fills LDS, so ONE 512-thread
+// workgroup is resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its
+// load, butterfly and store phases.  The 512-point kernels therefore request the next tile into a
+// second register set behind their first exchange; the loads travel during the remaining two passes
+// and the stores.  For that the barriers of the exchanges must not drain the vector-memory counter
+// (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
+// (tile_root) instead of read from the tables.
+// (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
+// pass -6 %, middle passes +6 % -- and keep the plain loop.)
+template <typename T, int LOG2G, int LOG2C, int MODE> constexpr bool tile_prefetches()
+{
+    using TC = TileCfg<T, LOG2G>;
+    using RD = typename TC::RD;
+    constexpr int G = TC::G, C = 1 << LOG2C, BLOCK = TC::TX * C;
+    constexpr int LDS_ELEMS = tile_pitch<C>() == C ? tile_colpitch<G>() * C : (lds_pad<kPadShift>(G - 1) + 1) * tile_pitch<C>();
+    constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
+                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER) || (MFFT_TILE_PF_GEN != 0 && MODE == TM_LAST_GEN) ||
+                              MODE == TM_FIRST_HANN;
+    constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(cx<T>) > 160 * 1024;
+    return MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && ONE_WG && BLOCK == 512 && RD::npass >= 3 && PLAIN_IN;
+}
+
 template <typename T, int LOG2G, int LOG2C, int MODE>
 __global__ void __launch_bounds__(((TileCfg<T, LOG2G>::TX) << LOG2C), (tile_min_waves<T, ((TileCfg<T, LOG2G>::TX) << LOG2C), MODE>()))
 fft_tile_kernel(const TArgs<T> a)
@@ -313,20 +336,7 @@ fft_tile_kernel(const TArgs<T> a)
     constexpr int NPASS = RD::npass;
     constexpr int COLPITCH = tile_colpitch<G>();
     constexpr int LDS_ELEMS = PITCH == C ? COLPITCH * C : (lds_pad<PADSHIFT>(G - 1) + 1) * PITCH;
-    // Prefetch.  A complex128 tile of 512 points x 16 columns or 256 x 32 fills LDS, so ONE 512-thread
-    // workgroup is resident per CU -- two waves per SIMD, 256 registers each -- and nothing overlaps its
-    // load, butterfly and store phases.  The 512-point kernels therefore request the next tile into a
-    // second register set behind their first exchange; the loads travel during the remaining two passes
-    // and the stores.  For that the barriers of the exchanges must not drain the vector-memory counter
-    // (tile_barrier<true>), and nothing else inside the loop may load: the twiddle roots are evaluated
-    // (tile_root) instead of read from the tables.
-    constexpr bool PLAIN_IN = MODE == TM_MID || MODE == TM_FIRST_PLAIN || MODE == TM_LAST_PLAIN || MODE == TM_LAST_TWID ||
-                              (MFFT_TILE_PF_POWER != 0 && MODE == TM_LAST_POWER) || (MFFT_TILE_PF_GEN != 0 && MODE == TM_LAST_GEN) ||
-                              MODE == TM_FIRST_HANN;
-    // (The 256 x 32 tiles, two passes and one exchange, measured no gain -- 2^24: -1..2 %, 2^31: first
-    // pass -6 %, middle passes +6 % -- and keep the plain loop.)
-    constexpr bool ONE_WG = 2 * (size_t)LDS_ELEMS * sizeof(C_) > 160 * 1024;
-    constexpr bool PF = MFFT_TILE_PREFETCH != 0 && MFFT_DIAG_NOFFT == 0 && sizeof(T) == 8 && ONE_WG && BLOCK == 512 && NPASS >= 3 && PLAIN_IN;
+    constexpr bool PF = tile_prefetches<T, LOG2G, LOG2C, MODE>();
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C_* lds = reinterpret_cast<C_*>(smem_raw);
@@ -856,7 +866,12 @@ int launch_tile_one(const TArgs<T>& a, hipStream_t s)
     }
     const int64_t total = a.batch << a.log2_tiles;
     if (total <= 0) return MFFT_OK;
-    const int grid = pick_grid(per_cu, total);
+    // The prefetching kernels chain one tile's loads behind the previous tile's exchanges and want exactly
+    // one resident set of workgroups striding over the tiles; the others gain 1.5-4 % from a grid several
+    // times that, which lets the dispatcher even out the tails (2^24: 141.8 -> 139.7 us, 2^26: 650 -> 623 us),
+    // and the four-column tiles of large batches 14 % from twice as many again (2^19 x 128: 485 -> 415 us).
+    const int over = tile_prefetches<T, LOG2G, LOG2C, MODE>() ? 1 : (LOG2C <= 2 ? 2 : 1) * a.grid_over;
+    const int grid = pick_grid(per_cu, total, over);
     if (a.buf) {
         // byte offsets of the buffer form stay below 2^32: G rows of L elements in, G rows of NS (or out_pitch) out
         const int64_t nso = (MODE == TM_LAST_PLAIN) ? (a.NS >> a.log2_w) * a.out_pitch : a.NS;

@@ -34,6 +34,7 @@ template <typename T> struct WaveArgs {
     const T* win;          // WIN: window of N samples
     int64_t units;         // 16-byte units in the whole batch = batch * N / K
     T scale;
+    int grid_over;         // host only: resident sets of workgroups to launch, 0 = the measured default
 };
 
 // value of lane (lane ^ MASK), MASK in {1, 2, 4, 8, 16, 32}
@@ -180,7 +181,12 @@ int launch_wave_one(const WaveArgs<T>& a, hipStream_t s)
     const int64_t steps = (a.units + 63) / 64;       // wave steps
     if (steps <= 0) return MFFT_OK;
     const int64_t groups = (steps + 4 * UNROLL - 1) / (4 * UNROLL);   // four waves per workgroup
-    hipLaunchKernelGGL(kern, dim3(pick_grid(per_cu, groups)), dim3(256), 0, s, a);
+    // Several resident sets of workgroups instead of one that strides over the batch: the dispatcher then
+    // evens out the CUs' different speeds (measured on 2^26-byte-pair batches: 8..17 % up to 64 points;
+    // at 128 complex64 points only the power-output forms gain, 7..8 %).
+    constexpr int over = sizeof(T) == 4 ? (LOG2N <= 5 ? 16 : LOG2N == 6 ? 8 : POWER ? 8 : 1)
+                                        : (LOG2N <= 5 ? 16 : POWER ? 4 : 8);
+    hipLaunchKernelGGL(kern, dim3(pick_grid(per_cu, groups, a.grid_over > 0 ? a.grid_over : over)), dim3(256), 0, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;
 }

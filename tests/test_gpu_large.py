@@ -154,7 +154,9 @@ def test_first_pass_with_evaluated_window_and_range_checked_loads(fa, monkeypatc
     ("MFFT_TILE_BUF", "12", "c128_2p20"), ("MFFT_TILE_NT", "0", "c64_2p20"), ("MFFT_TILE_NT", "3", "c128_2p20"),
     ("MFFT_TILE_NT_PASS", "1,3,2", "c64_2p20"), ("MFFT_WORK2", "1", "c64_2p20"), ("MFFT_R2C_FROM", "30", "real_2p17"),
     ("MFFT_BALANCED_COLUMNS", "1", "columns"), ("MFFT_NARROW_COLUMNS", "1", "columns"),
-    ("MFFT_COPY_THREADS", "1", "host_path"), ("MFFT_COPY_STREAM", "0", "host_path")])
+    ("MFFT_COPY_THREADS", "1", "host_path"), ("MFFT_COPY_STREAM", "0", "host_path"),
+    ("MFFT_TILE_GRID_OVER", "1", "c64_2p22"), ("MFFT_TILE_GRID_OVER", "3", "c64_2p22"), ("MFFT_TILE_GRID_OVER", "64", "c64_2p19"),
+    ("MFFT_LDS_GRID_OVER", "1", "lds_batches"), ("MFFT_LDS_GRID_OVER", "3", "lds_batches"), ("MFFT_LDS_GRID_OVER", "64", "lds_batches")])
 def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, case):
     """Every variable the library reads when a plan is built or executed (tuning aids: pass splits, cache policies,
     access forms, routes) selects another way to the same bins: np.fft.fft (final2.py:143) stays the reference."""
@@ -164,13 +166,20 @@ def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, c
 
     def cplx(shape, cdt):
         return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(cdt)
-    if case in ("c64_2p19", "c64_2p20", "c128_2p20"):
+    if case in ("c64_2p19", "c64_2p20", "c64_2p22", "c128_2p20"):
         dtype = 0 if case.startswith("c64") else 1
         n = 1 << int(case[-2:])
         x = cplx((2, n), np.complex64 if dtype == 0 else np.complex128)
         with fa.Plan(n, batch=2, dtype=dtype) as p:
             y = p.exec_host(x)
         assert rel_l2(y, np.fft.fft(x.astype(np.complex128), axis=-1)) < TOL[dtype]
+    elif case == "lds_batches":             # more workgroups than one resident set, at a lane-distributed and two LDS lengths
+        for n, batch, dtype, flags in ((32, 70001, 0, 0), (512, 9001, 0, fa.HANN | fa.POWER), (2048, 1501, 1, 0), (8192, 700, 0, 0)):
+            x = cplx((batch, n), np.complex64 if dtype == 0 else np.complex128)
+            ref = np.fft.fft(x.astype(np.complex128) * (np.hanning(n) if flags & fa.HANN else 1.0), axis=-1)
+            with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
+                y = p.exec_host(x)
+            assert rel_l2(y, np.abs(ref) ** 2 if flags & fa.POWER else ref) < TOL[dtype], (n, batch)
     elif case == "padded_window":
         n, n_in = 1 << 17, 100001
         x = cplx((3, n_in), np.complex64)
