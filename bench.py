@@ -766,7 +766,7 @@ def main(argv=None):
                    "n": n, "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kern_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg_bytes / kern_avg_s / 1e9 / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "kernel": "fft_lds_kernel (hann+power)",
+                     "traffic": traffic, "traffic_source": traffic_source, "kernel": "fft_lds_tail_kernel (hann+power)",
                      "kernel_ms_avg": kern_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }

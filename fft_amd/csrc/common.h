@@ -71,6 +71,11 @@ template <typename T> struct KArgs {
     // (j & ((1 << lseg) - 1)); lseg = 30 describes a dense signal.
     int in_lseg, out_lseg;
     int grid_over;         // host only: resident sets of workgroups to launch, 0 = the measured default (lds_grid_over)
+    // Set by the launcher: workgroups below `resident` stride (by `resident`) over the groups below tail_start,
+    // each further one takes tail_chunk consecutive groups from tail_start on.
+    int64_t tail_start;
+    int resident, tail_chunk;
+    int tail_pct, tail_chunk_req;      // host only (tuning aid): share of the batch left to the tail (-1 none, 0 the kernel's default), groups per tail workgroup
 };
 
 // Segments the plain segmented variant (V_SEG) serves without staging: powers of two up to 2^30 that hold

@@ -524,8 +524,9 @@ template <typename T, int N, int VAR> constexpr bool prefetch_default()
 // everything outstanding.  (Measured and not kept: requesting half of the next signal already when
 // the butterflies begin, into LDS freed by exchanging through a half-size buffer -- twice the
 // barriers; 16384 points plain 215.8 against 215.4 us, Hann 201 against 212, Hann + power 184 against 181.)
-template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR, bool DMA = false>
-__global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
+// The kernel's body over the groups g_first, g_first + g_step, ... below g_end (all three uniform).
+template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR, bool DMA>
+__device__ __forceinline__ void lds_body(const KArgs<T>& a, const int64_t g_first, const int64_t g_end, const unsigned g_step)
 {
     using C = cx<T>;
     constexpr int N = RD::n;
@@ -590,7 +591,6 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         if constexpr (NPASS > 3) preload_twiddles<T, RD, 3, P, TX>(twr, t, a.tw);
     }
 
-    const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
     // Load of one signal in the fast variants (pass-0 inputs: positions t + TX*e).  A slot beyond the
     // batch re-reads the last signal and skips its stores: no branch here.
     const auto load_fast = [&](C (&dst)[P], int64_t bsig) {
@@ -627,7 +627,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
                                                              : (((MFFT_PREFETCH & 1) != 0 && TX <= 64) || ((MFFT_PREFETCH & 2) != 0 && TX > 64)));
     C vn[PREFETCH ? P : 1];
     if constexpr (PREFETCH) {
-        if ((int64_t)blockIdx.x < groups) load_fast(vn, (int64_t)blockIdx.x * SLOTS + slot);
+        if (g_first < g_end) load_fast(vn, g_first * SLOTS + slot);
     }
     // LDS-DMA of one signal into the (then idle) exchange buffer as a lane-linear image: element j at
     // byte j * sizeof(C).  A piece is one wave-instruction = 1 KiB = PE consecutive elements, which lie
@@ -672,11 +672,11 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         }
     };
     if constexpr (DMA) {
-        if ((int64_t)blockIdx.x < groups) dma_signal((int64_t)blockIdx.x);
+        if (g_first < g_end) dma_signal(g_first);
         wait_vm<0>();
         lds_barrier();
     }
-    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    for (int64_t g = g_first; g < g_end; g += g_step) {
         const int64_t b = g * SLOTS + slot;
         const bool active = b < a.batch;
         C v[P];
@@ -693,7 +693,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = stage[tl + TX * e];
             if constexpr (WARM) {
-                if (g + gridDim.x < groups) dma_warm(g + gridDim.x);
+                if (g + g_step < g_end) dma_warm(g + g_step);
             }
             if constexpr (FASTWIN) {
 #pragma unroll
@@ -705,7 +705,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = vn[e];
                 // the group after this one (re-reads this one at the end of the batch: no branch)
-                const int64_t gn = g + gridDim.x < groups ? g + gridDim.x : g;
+                const int64_t gn = g + g_step < g_end ? g + g_step : g;
                 load_fast(vn, gn * SLOTS + slot);
             } else {
                 load_fast(v, b);
@@ -803,7 +803,7 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
         // the exchange buffer is idle from the last exchange on: the workgroup's next signal goes there
         const auto dma_next = [&]() {
             lds_barrier();                                  // every wave has read its exchange results
-            if (g + gridDim.x < groups) dma_signal(g + gridDim.x);
+            if (g + g_step < g_end) dma_signal(g + g_step);
         };
 #if !MFFT_DIAG_NOFFT
         const auto exchange = [&](auto pass) {
@@ -1073,6 +1073,33 @@ __global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KA
 #endif
 }
 
+// One resident set of workgroups, or several, all striding over the batch.
+template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR, bool DMA = false>
+__global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_kernel(const KArgs<T> a)
+{
+    constexpr int SLOTS = BLOCK / (RD::n / P);
+    lds_body<T, P, RD, PADSHIFT, BLOCK, VAR, DMA>(a, (int64_t)blockIdx.x, (a.batch + SLOTS - 1) / SLOTS, gridDim.x);
+}
+
+// The same with a tail: the first a.resident workgroups stride over the groups below a.tail_start, every
+// further workgroup takes a.tail_chunk consecutive groups of the rest.  Those are dispatched as the
+// striding workgroups of the faster CUs end, so the last part of the batch goes to whoever is free, while
+// the bulk pays for tables and window registers once per resident workgroup.  (Two copies of the body:
+// one loop with a selected start, end and step schedules measurably worse than the plain striding loop.)
+template <typename T, int P, class RD, int PADSHIFT, int BLOCK, int VAR>
+__global__ void MFFT_LAUNCH_BOUNDS(BLOCK, T, RD::n, VAR) fft_lds_tail_kernel(const KArgs<T> a)
+{
+    constexpr int SLOTS = BLOCK / (RD::n / P);
+    const unsigned res = (unsigned)a.resident;
+    if (blockIdx.x < res) {
+        lds_body<T, P, RD, PADSHIFT, BLOCK, VAR, false>(a, (int64_t)blockIdx.x, a.tail_start, res);
+    } else {
+        const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
+        const int64_t g0 = a.tail_start + (int64_t)(blockIdx.x - res) * a.tail_chunk;
+        lds_body<T, P, RD, PADSHIFT, BLOCK, VAR, false>(a, g0, g0 + a.tail_chunk < groups ? g0 + a.tail_chunk : groups, 1u);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Size table: P points per thread and the pass radices for each 2^k.
 // ---------------------------------------------------------------------------
@@ -1181,6 +1208,18 @@ template <typename T, int LOG2N, int VAR, bool DMA> constexpr int lds_grid_over(
     return sizeof(T) == 4 ? c64[VAR][L] : c128[VAR][L];
 }
 
+// Which kernels are also built with a tail (fft_lds_tail_kernel), the share of the batch it gets (per cent)
+// and the groups per tail workgroup.
+template <typename T, int LOG2N, int VAR> constexpr bool lds_tail_built()
+{
+    return sizeof(T) == 4 && LOG2N >= 9 && LOG2N <= 12 && (VAR == V_HANN_POWER || VAR == V_HANN_POWER_STATS);
+}
+// (measured, tail share in per cent / groups per tail workgroup against none, 2^26 points per launch: 512 points
+// 2/1 136.5 -> 134.4 us, 1024 points 2/1 .. 4/1 135.6 -> 134.2, 2048 points 16/2 141.3 -> 138.3, 4096 points
+// 10/2 147.7 -> 145.1 and with statistics 163.4 -> 157.8; larger shares lose to the tail workgroups' start-up)
+template <typename T, int LOG2N, int VAR> constexpr int lds_tail_pct() { return LOG2N == 9 ? 2 : LOG2N == 10 ? 3 : LOG2N == 11 ? 16 : 10; }
+template <typename T, int LOG2N, int VAR> constexpr int lds_tail_chunk() { return LOG2N >= 11 ? 2 : 1; }
+
 // The LDS-DMA pipeline moves 16 bytes per lane: signals (and segments) must start on 16-byte boundaries.
 // MFFT_NO_DMA=1 in the environment selects the register-load form (A/B timing, tests).
 template <typename T, int VAR> bool dma_usable(const KArgs<T>& a)
@@ -1221,6 +1260,26 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
     const int64_t groups = (a.batch + SLOTS - 1) / SLOTS;
     if (groups <= 0) return MFFT_OK;
     if (grid <= 0) grid = pick_grid(per_cu, groups, a.grid_over > 0 ? a.grid_over : lds_grid_over<T, LOG2N, VAR, DMA>());
+    if constexpr (!DMA && lds_tail_built<T, LOG2N, VAR>()) {
+        // striding bulk + tail handed out by the dispatcher
+        const int pct = a.tail_pct > 0 ? a.tail_pct : a.tail_pct == 0 ? lds_tail_pct<T, LOG2N, VAR>() : 0;
+        const int chunk = a.tail_chunk_req > 0 ? a.tail_chunk_req : lds_tail_chunk<T, LOG2N, VAR>();
+        const int64_t res = pick_grid(per_cu, groups, 1);
+        const int64_t tail = groups * pct / 100;
+        if (pct > 0 && a.grid_over <= 0 && res < groups && tail > 0 && res + (tail + chunk - 1) / chunk < (int64_t(1) << 31)) {
+            auto tkern = fft_lds_tail_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
+            static thread_local int tattr_dev = -1;
+            if (tattr_dev != dev) {
+                MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                tattr_dev = dev;
+            }
+            KArgs<T> h = a;
+            h.resident = (int)res; h.tail_chunk = chunk; h.tail_start = groups - tail;
+            hipLaunchKernelGGL(tkern, dim3((unsigned)(res + (tail + chunk - 1) / chunk)), dim3(BLOCK), lds, s, h);
+            MFFT_HIP(hipGetLastError());
+            return MFFT_OK;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, a);
     MFFT_HIP(hipGetLastError());
     return MFFT_OK;

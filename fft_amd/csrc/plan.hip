@@ -218,6 +218,8 @@ struct Pow2Engine {
     int tile_nt = 0;                    // TArgs::nt of the plain tile passes
     int tile_nt_pass[4] = {-1, -1, -1, -1};   // per-pass value where it differs from tile_nt (-1: tile_nt)
     int narrow = 0;                     // tile width bits (TArgs::narrow)
+    int tail_pct = 0, tail_chunk = 0;   // MFFT_LDS_TAIL=pct,chunk at build (tuning aid): share of the batch the tail workgroups of fft_lds_tail_kernel get
+                                        // (negative: none, 0: per length) and the groups each of them takes
     int lds_over = 0;                   // MFFT_LDS_GRID_OVER at build (tuning aid): the same for the single-kernel transforms, 0 = per length and variant
     int grid_over = 4;                  // MFFT_TILE_GRID_OVER at build (tuning aid): resident sets of workgroups a non-prefetching tile pass is launched with
     int tile_buf = -1;                  // MFFT_TILE_BUF at build (tuning aid): TArgs::buf of every pass; -1 = by tile width and data size
@@ -341,6 +343,7 @@ int Pow2Engine::build(int64_t n_, int64_t batch_, int dtype_, int64_t inner_, in
     log2n = ilog2(n);
     table_window = getenv("MFFT_TABLE_WINDOW") != nullptr;
     if (const char* e = getenv("MFFT_TILE_BUF")) tile_buf = atoi(e);
+    if (const char* e = getenv("MFFT_LDS_TAIL")) { if (sscanf(e, "%d,%d", &tail_pct, &tail_chunk) != 2) tail_pct = tail_chunk = 0; }
     if (const char* e = getenv("MFFT_LDS_GRID_OVER")) lds_over = atoi(e) < 0 ? 0 : atoi(e) > 64 ? 64 : atoi(e);
     if (const char* e = getenv("MFFT_TILE_GRID_OVER")) grid_over = atoi(e) < 1 ? 1 : atoi(e) > 64 ? 64 : atoi(e);
     if (!is_pow2(n) || n < 2) { set_error("engine length must be a power of two >= 2"); return MFFT_E_INVALID; }
@@ -480,6 +483,7 @@ template <typename T> int Pow2Engine::exec(const Io<T>& io, hipStream_t s)
         a.real_in = io.real_in; a.conj_in = io.conj_in; a.conj_out = io.conj_out;
         a.scale = io.scale;
         a.grid_over = lds_over;
+        a.tail_pct = tail_pct; a.tail_chunk_req = tail_chunk;
         const bool full = io.n_in == n && io.n_out == n && io.in_stride == n && io.out_stride == n &&
                           io.in_seg == 0 && io.out_seg == 0;
         const bool bare_or_stats = !io.pre && !io.post && !io.real_in && !io.conj_in && !io.conj_out && full;

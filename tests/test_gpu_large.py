@@ -156,7 +156,8 @@ def test_first_pass_with_evaluated_window_and_range_checked_loads(fa, monkeypatc
     ("MFFT_BALANCED_COLUMNS", "1", "columns"), ("MFFT_NARROW_COLUMNS", "1", "columns"),
     ("MFFT_COPY_THREADS", "1", "host_path"), ("MFFT_COPY_STREAM", "0", "host_path"),
     ("MFFT_TILE_GRID_OVER", "1", "c64_2p22"), ("MFFT_TILE_GRID_OVER", "3", "c64_2p22"), ("MFFT_TILE_GRID_OVER", "64", "c64_2p19"),
-    ("MFFT_LDS_GRID_OVER", "1", "lds_batches"), ("MFFT_LDS_GRID_OVER", "3", "lds_batches"), ("MFFT_LDS_GRID_OVER", "64", "lds_batches")])
+    ("MFFT_LDS_GRID_OVER", "1", "lds_batches"), ("MFFT_LDS_GRID_OVER", "3", "lds_batches"), ("MFFT_LDS_GRID_OVER", "64", "lds_batches"),
+    ("MFFT_LDS_TAIL", "-1,1", "lds_batches"), ("MFFT_LDS_TAIL", "30,3", "lds_batches"), ("MFFT_LDS_TAIL", "100,1", "lds_batches")])
 def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, case):
     """Every variable the library reads when a plan is built or executed (tuning aids: pass splits, cache policies,
     access forms, routes) selects another way to the same bins: np.fft.fft (final2.py:143) stays the reference."""
@@ -174,7 +175,8 @@ def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, c
             y = p.exec_host(x)
         assert rel_l2(y, np.fft.fft(x.astype(np.complex128), axis=-1)) < TOL[dtype]
     elif case == "lds_batches":             # more workgroups than one resident set, at a lane-distributed and two LDS lengths
-        for n, batch, dtype, flags in ((32, 70001, 0, 0), (512, 9001, 0, fa.HANN | fa.POWER), (2048, 1501, 1, 0), (8192, 700, 0, 0)):
+        for n, batch, dtype, flags in ((32, 70001, 0, 0), (512, 9001, 0, fa.HANN | fa.POWER), (4096, 1201, 0, fa.HANN | fa.POWER),
+                                      (2048, 1501, 1, 0), (8192, 700, 0, 0)):
             x = cplx((batch, n), np.complex64 if dtype == 0 else np.complex128)
             ref = np.fft.fft(x.astype(np.complex128) * (np.hanning(n) if flags & fa.HANN else 1.0), axis=-1)
             with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:

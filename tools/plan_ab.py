@@ -11,7 +11,7 @@
 
 Variables: MFFT_SPLIT (log2 radices of the global passes), MFFT_TILE_NT / MFFT_TILE_NT_PASS (cache policy per pass:
 bit 0 streaming loads, bit 1 streaming stores), MFFT_FOUR_PASSES, MFFT_NO_NARROW_RADIX, MFFT_BALANCED_COLUMNS,
-MFFT_NARROW_COLUMNS, MFFT_WORK2, MFFT_TABLE_WINDOW, MFFT_NO_R2C, MFFT_NO_WAVE, MFFT_TILE_GRID_OVER (resident sets of workgroups per tile pass), MFFT_TILE_BUF (0 global accesses, 4 buffer-form
+MFFT_NARROW_COLUMNS, MFFT_WORK2, MFFT_TABLE_WINDOW, MFFT_NO_R2C, MFFT_NO_WAVE, MFFT_TILE_GRID_OVER / MFFT_LDS_GRID_OVER (resident sets of workgroups per tile pass / single-kernel transform), MFFT_LDS_TAIL (pct,chunk), MFFT_TILE_BUF (0 global accesses, 4 buffer-form
 loads, 12 and stores), and -- read at execution --
 MFFT_NO_DMA, MFFT_GENERAL_PROLOGUE.
 "default" leaves the variable unset.  --n-in zero-pads; flags as in include/mfft.h (1 Hann, 2 power, 8 real input,
