@@ -1264,15 +1264,16 @@ int launch_one(const KArgs<T>& a, int grid, hipStream_t s)
         // striding bulk + tail handed out by the dispatcher
         const int pct = a.tail_pct > 0 ? a.tail_pct : a.tail_pct == 0 ? lds_tail_pct<T, LOG2N, VAR>() : 0;
         const int chunk = a.tail_chunk_req > 0 ? a.tail_chunk_req : lds_tail_chunk<T, LOG2N, VAR>();
-        const int64_t res = pick_grid(per_cu, groups, 1);
+        auto tkern = fft_lds_tail_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
+        static thread_local int tattr_dev = -1, tper_cu = 1;
+        if (tattr_dev != dev) {
+            MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            tper_cu = blocks_per_cu(reinterpret_cast<const void*>(tkern), BLOCK, lds);      // the striding set must be resident at once
+            tattr_dev = dev;
+        }
+        const int64_t res = pick_grid(tper_cu, groups, 1);
         const int64_t tail = groups * pct / 100;
         if (pct > 0 && a.grid_over <= 0 && res < groups && tail > 0 && res + (tail + chunk - 1) / chunk < (int64_t(1) << 31)) {
-            auto tkern = fft_lds_tail_kernel<T, points_per_thread<T, LOG2N, VAR>(), typename SC::RD, kPadShift, BLOCK, VAR>;
-            static thread_local int tattr_dev = -1;
-            if (tattr_dev != dev) {
-                MFFT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                tattr_dev = dev;
-            }
             KArgs<T> h = a;
             h.resident = (int)res; h.tail_chunk = chunk; h.tail_start = groups - tail;
             hipLaunchKernelGGL(tkern, dim3((unsigned)(res + (tail + chunk - 1) / chunk)), dim3(BLOCK), lds, s, h);
