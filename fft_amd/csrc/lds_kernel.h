@@ -1176,11 +1176,13 @@ int pick_grid(int per_cu, int64_t groups, int over = 1);
 // registers, the drain of the last stores) was measured per length and variant on 2^26 (complex64) /
 // 2^25 (complex128) points per launch, factors 1, 2, 4, 8, 16: the light variants gain 5..12 % at 8..16
 // sets, the windowed power variants from 512 points (window samples and twiddles in registers: the
-// heaviest start-up, two workgroups per CU) lose 3..15 % and keep one set; the LDS-DMA kernels gain 1..5 %
-// at two sets and lose from four.  Columns: log2 of the length.
+// heaviest start-up, two workgroups per CU) lose 3..15 % and keep one set; the LDS-DMA kernels lose from four.
+// Columns: log2 of the length.
 template <typename T, int LOG2N, int VAR, bool DMA> constexpr int lds_grid_over()
 {
-    if (DMA) return 2;
+    // LDS-DMA kernels: two sets where the output is complex (8192 points +3..7 %, 16384 points plain +1..2.5 %);
+    // with power output, and windowed at 16384 points, two sets measured -2.4..+2.3 % from run to run: one
+    if (DMA) return (VAR == V_PLAIN || VAR == V_SEG || (VAR == V_WIN && LOG2N < 14)) ? 2 : 1;
     constexpr int L = LOG2N > 14 ? 14 : LOG2N;
     //                                0   1   2   3   4   5   6   7   8   9  10  11  12  13  14
     constexpr signed char c64[V_COUNT][15] = {
@@ -1191,17 +1193,17 @@ template <typename T, int LOG2N, int VAR, bool DMA> constexpr int lds_grid_over(
         /* V_SEG              */ { 1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1},
         /* V_WIN              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  8,  8,  1,  1,  1},
         /* V_POW              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  8,  8,  4,  1,  1},
-        /* V_REAL             */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  1, 16,  8,  1,  1},
+        /* V_REAL             */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  8,  8, 16,  8,  1,  1},
         /* V_HANN_POWER_STATS */ {16, 16, 16, 16, 16,  1,  4,  8,  8,  1,  1,  1,  1,  1,  1},
         /* V_POW_STATS        */ {16, 16, 16, 16, 16,  8,  8, 16, 16,  4,  8,  8,  4,  1,  1}};
     constexpr signed char c128[V_COUNT][15] = {
         /* V_PLAIN            */ {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16,  8, 16,  1,  1},
         /* V_HANN_POWER       */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  1,  2,  1,  1,  1,  1},
-        /* V_GEN_CPLX         */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
-        /* V_GEN_POWER        */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
+        /* V_GEN_CPLX         */ { 8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  1,  1},
+        /* V_GEN_POWER        */ { 8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  8,  1,  1},
         /* V_SEG              */ { 1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1},
         /* V_WIN              */ {16, 16, 16, 16, 16, 16, 16, 16, 16,  4,  8,  8,  4,  1,  1},
-        /* V_POW              */ { 8,  8,  8,  8,  8,  8,  8,  8, 16, 16,  2,  1,  2,  1,  1},
+        /* V_POW              */ { 8,  8,  8,  8,  8,  8,  8,  8, 16, 16,  2, 16,  2,  1,  1},
         /* V_REAL             */ { 4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  4,  1,  1},
         /* V_HANN_POWER_STATS */ { 8,  8,  8,  8,  8,  8,  8, 16, 16,  4,  2,  1,  1,  1,  1},
         /* V_POW_STATS        */ { 8,  8,  8,  8,  8, 16,  8, 16, 16, 16,  1,  1,  1,  1,  1}};
