@@ -1214,13 +1214,18 @@ template <typename T, int LOG2N, int VAR, bool DMA> constexpr int lds_grid_over(
 // and the groups per tail workgroup.
 template <typename T, int LOG2N, int VAR> constexpr bool lds_tail_built()
 {
-    return sizeof(T) == 4 && LOG2N >= 9 && LOG2N <= 12 && (VAR == V_HANN_POWER || VAR == V_HANN_POWER_STATS);
+    return LOG2N >= (sizeof(T) == 4 ? 9 : 11) && LOG2N <= 12 && (VAR == V_HANN_POWER || VAR == V_HANN_POWER_STATS);
 }
 // (measured, tail share in per cent / groups per tail workgroup against none, 2^26 points per launch: 512 points
 // 2/1 136.5 -> 134.4 us, 1024 points 2/1 .. 4/1 135.6 -> 134.2, 2048 points 16/2 141.3 -> 138.3, 4096 points
 // 10/2 147.7 -> 145.1 and with statistics 163.4 -> 157.8; larger shares lose to the tail workgroups' start-up)
-template <typename T, int LOG2N, int VAR> constexpr int lds_tail_pct() { return LOG2N == 9 ? 2 : LOG2N == 10 ? 3 : LOG2N == 11 ? 16 : 10; }
-template <typename T, int LOG2N, int VAR> constexpr int lds_tail_chunk() { return LOG2N >= 11 ? 2 : 1; }
+// complex128 (2^25 points per launch): 2048 points 8/1 142.8 -> 139.2, 4096 points 4/1 149.1 -> 145.2; none at 512 / 1024 (-0.5..-4 %)
+template <typename T, int LOG2N, int VAR> constexpr int lds_tail_pct()
+{
+    if (sizeof(T) == 8) return LOG2N == 11 ? 8 : 4;
+    return LOG2N == 9 ? 2 : LOG2N == 10 ? 3 : LOG2N == 11 ? 16 : 10;
+}
+template <typename T, int LOG2N, int VAR> constexpr int lds_tail_chunk() { return sizeof(T) == 4 && LOG2N >= 11 ? 2 : 1; }
 
 // The LDS-DMA pipeline moves 16 bytes per lane: signals (and segments) must start on 16-byte boundaries.
 // MFFT_NO_DMA=1 in the environment selects the register-load form (A/B timing, tests).

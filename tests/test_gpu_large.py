@@ -176,7 +176,7 @@ def test_tuning_variables_leave_results_unchanged(fa, monkeypatch, var, value, c
         assert rel_l2(y, np.fft.fft(x.astype(np.complex128), axis=-1)) < TOL[dtype]
     elif case == "lds_batches":             # more workgroups than one resident set, at a lane-distributed and two LDS lengths
         for n, batch, dtype, flags in ((32, 70001, 0, 0), (512, 9001, 0, fa.HANN | fa.POWER), (4096, 1201, 0, fa.HANN | fa.POWER),
-                                      (2048, 1501, 1, 0), (8192, 700, 0, 0)):
+                                      (2048, 1501, 1, 0), (2048, 2203, 1, fa.HANN | fa.POWER), (8192, 700, 0, 0)):
             x = cplx((batch, n), np.complex64 if dtype == 0 else np.complex128)
             ref = np.fft.fft(x.astype(np.complex128) * (np.hanning(n) if flags & fa.HANN else 1.0), axis=-1)
             with fa.Plan(n, batch=batch, dtype=dtype, flags=flags) as p:
