@@ -40,12 +40,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--min-log2n", type=int, default=4)
+    ap.add_argument("--max-log2n", type=int, default=14)
     args = ap.parse_args()
     out = {}
     for dtype in (0, 1):
         cdt = torch.complex64 if dtype == 0 else torch.complex128
         rdt = torch.float32 if dtype == 0 else torch.float64
-        for log2n in range(args.min_log2n, 15 if dtype == 0 else 14):
+        for log2n in range(args.min_log2n, min(args.max_log2n, 14 if dtype == 0 else 13) + 1):
             n = 1 << log2n
             batch = (1 << (26 if dtype == 0 else 25)) >> log2n
             for flags in (0, 1, 2, 3, 8, 18, 19):
