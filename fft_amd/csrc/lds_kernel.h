@@ -33,6 +33,9 @@
 #ifndef MFFT_WAVES_PER_EU
 #define MFFT_WAVES_PER_EU 0  // 0 = let the compiler choose; k = cap VGPRs for k waves per SIMD
 #endif
+#ifndef MFFT_BLOCK_1024_HANN
+#define MFFT_BLOCK_1024_HANN 64   // workgroup size of the 1024-point complex64 Hann + power kernels (one wave = one signal)
+#endif
 #ifndef MFFT_BLOCK_MIN
 #define MFFT_BLOCK_MIN 256   // workgroup size when a signal needs fewer threads than this
 #endif
@@ -1151,7 +1154,11 @@ template <typename T, int LOG2N, int VAR = V_PLAIN> struct BlockCfg {
     static constexpr int TX = (1 << LOG2N) / points_per_thread<T, LOG2N, VAR>();
     // a two-wave signal (2048 points) gets a workgroup of its own: its barriers then span two
     // waves instead of four (+4 % plain complex64); one-wave signals need no barrier and share
-    static constexpr int BLOCK = (TX == 128 && MFFT_BLOCK_2048 != 0) ? 128 : (TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN);
+    // (the 1024-point complex64 Hann + power kernels: one-wave workgroups, so that the dispatched tail is handed out
+    // signal by signal)
+    static constexpr bool ONE_WAVE = sizeof(T) == 4 && LOG2N == 10 && (VAR == V_HANN_POWER || VAR == V_HANN_POWER_STATS);
+    static constexpr int BLOCK = ONE_WAVE ? MFFT_BLOCK_1024_HANN
+                               : (TX == 128 && MFFT_BLOCK_2048 != 0) ? 128 : (TX > MFFT_BLOCK_MIN ? TX : MFFT_BLOCK_MIN);
 };
 
 template <typename T, int LOG2N, int VAR = V_PLAIN> constexpr size_t lds_bytes_for()
@@ -1223,9 +1230,15 @@ template <typename T, int LOG2N, int VAR> constexpr bool lds_tail_built()
 template <typename T, int LOG2N, int VAR> constexpr int lds_tail_pct()
 {
     if (sizeof(T) == 8) return LOG2N == 11 ? 8 : 4;
-    return LOG2N == 9 ? 2 : LOG2N == 10 ? 3 : LOG2N == 11 ? 16 : 10;
+    return LOG2N == 9 ? 2 : LOG2N == 10 ? 6 : LOG2N == 11 ? 16 : 10;
 }
-template <typename T, int LOG2N, int VAR> constexpr int lds_tail_chunk() { return sizeof(T) == 4 && LOG2N >= 11 ? 2 : 1; }
+// (1024 complex64 points run in one-wave workgroups, a group is one signal: 6 % in pairs 134.7 -> 131.7 us against
+// 133.2 for the best tail of 256-thread workgroups; with statistics 6 % in fours 145.7 -> 143.3 against 144.5)
+template <typename T, int LOG2N, int VAR> constexpr int lds_tail_chunk()
+{
+    if (sizeof(T) == 4 && LOG2N == 10) return VAR == V_HANN_POWER_STATS ? 4 : 2;
+    return sizeof(T) == 4 && LOG2N >= 11 ? 2 : 1;
+}
 
 // The LDS-DMA pipeline moves 16 bytes per lane: signals (and segments) must start on 16-byte boundaries.
 // MFFT_NO_DMA=1 in the environment selects the register-load form (A/B timing, tests).

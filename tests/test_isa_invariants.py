@@ -154,7 +154,7 @@ def test_prefetching_tile_kernels_request_the_next_tile_between_exchanges(tmp_pa
 # translation unit that instantiates every variant of a few sizes of each kernel family (a few seconds each).
 KNOB_SETS = [
     "-DMFFT_TW_SRC=2 -DMFFT_WIN_SRC=2 -DMFFT_PREFETCH=3 -DMFFT_AFFINE=1 -DMFFT_VEC=1 -DMFFT_FAST_BUF=1 -DMFFT_TILE_EVAL_ROOTS=1 "
-    "-DMFFT_BIG_RADIX=1 -DMFFT_TILE_PF_GEN=1 -DMFFT_P8192=16 -DMFFT_WAVES_PER_EU=2 -DMFFT_BLOCK_MIN=128 -DMFFT_WIN_BUF_FROM=4096 "
+    "-DMFFT_BIG_RADIX=1 -DMFFT_TILE_PF_GEN=1 -DMFFT_P8192=16 -DMFFT_WAVES_PER_EU=2 -DMFFT_BLOCK_MIN=128 -DMFFT_BLOCK_1024_HANN=256 -DMFFT_WIN_BUF_FROM=4096 "
     "-DMFFT_WAVE_UNROLL=2",
     "-DMFFT_TW_SRC=0 -DMFFT_PREFETCH=0 -DMFFT_AFFINE=0 -DMFFT_VEC=0 -DMFFT_NT=0 -DMFFT_DMA=0 -DMFFT_TILE_TW2=0 -DMFFT_TILE_VEC=0 "
     "-DMFFT_TILE_EVAL_ROOTS=0 -DMFFT_TILE_PREFETCH=0 -DMFFT_TILE_OCC=0 -DMFFT_STATS_F32=0 -DMFFT_STATS_CLOSED=0 "
