@@ -16,9 +16,11 @@
 // stores of different signals overlapped on a CU.  For TX > 64 the exchange is
 // bracketed by workgroup barriers.
 //
-// Workgroups are persistent: the grid is sized to the machine and every
-// workgroup strides over the batch, so per-lane constants (window samples,
-// twiddles) are fetched once into registers and reused for every signal.
+// Workgroups stride over the batch, so per-lane constants (window samples,
+// twiddles) are fetched once into registers and reused for every signal a
+// workgroup transforms.  How many workgroups a launch asks for -- one resident
+// set, several, or one set plus a tail the dispatcher hands out -- is measured
+// per length and variant (lds_grid_over, fft_lds_tail_kernel).
 #pragma once
 #include "common.h"
 #include <type_traits>
